@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the *reference* Python package.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU box).
+The reference is imported read-only from /root/reference/src with `quantum_attn.inductor`
+stubbed out (its Inductor lowering does not import on torch 2.10); everything
+stored here comes from the reference's own functions:
+
+  * quantum_attn.nn._dynamically_quantize_fp8          (eager numerics,    nn.py:14-19)
+  * quantum_attn.dynamically_quantize_fp8              (compiled numerics, nn.py:22-42)
+  * quantum_attn.ops._fp8_attention_forward            (semantic definition of the op, ops.py:64-95)
+  * quantum_attn.ops._attention_forward                (16-bit sibling op, ops.py:17-29)
+  * quantum_attn.*_with_fallback on CPU tensors        (interface.py:62-98,134-176,209-248)
+
+Outputs are data only (npz with raw bit patterns); no reference source is copied.
+Usage:  python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    sys.modules["quantum_attn.inductor"] = types.ModuleType("quantum_attn.inductor")
+    import quantum_attn  # noqa: F401
+
+    return quantum_attn
+
+
+def bits16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def bits8(t):
+    return t.contiguous().view(torch.uint8).numpy().copy()
+
+
+def main():
+    qa = import_reference()
+    from quantum_attn import nn as qnn, ops as qops
+
+    torch.set_num_threads(4)
+    cases = [
+        # name, B, H, Sq, Skv, D, dtype, seed, with_eager
+        ("c1_b1h2s128d64_bf16_s0", 1, 2, 128, 128, 64, torch.bfloat16, 0, True),
+        ("c1_b1h2s128d64_bf16_s1", 1, 2, 128, 128, 64, torch.bfloat16, 1, False),
+        ("c1_b1h2s128d64_fp16_s0", 1, 2, 128, 128, 64, torch.float16, 0, True),
+        ("b1h2s256d128_bf16_s0", 1, 2, 256, 256, 128, torch.bfloat16, 0, False),
+        ("ragged_b1h2s200d128_bf16_s1", 1, 2, 200, 200, 128, torch.bfloat16, 1, False),
+        ("cross_b1h2sq96skv160d128_bf16_s2", 1, 2, 96, 160, 128, torch.bfloat16, 2, False),
+    ]
+    for name, B, H, Sq, Skv, D, dtype, seed, with_eager in cases:
+        torch.manual_seed(seed)
+        # same construction as the reference's tests (tests/test_interface.py:40-43)
+        q = torch.randn(B, H, Sq, D, dtype=dtype)
+        k = torch.randn(B, H, Skv, D, dtype=dtype)
+        v = torch.randn(B, H, Skv, D, dtype=dtype)
+        out = {
+            "meta": np.array([B, H, Sq, Skv, D, 1 if dtype == torch.bfloat16 else 0, seed], dtype=np.int64),
+            "q": bits16(q), "k": bits16(k), "v": bits16(v),
+        }
+        for method, rdim in (("head", [2, 3]), ("token", 3)):
+            # compiled numerics == what the reference's GPU path runs (nn.py:521-539)
+            q8, sq = qa.dynamically_quantize_fp8(q, reduction_dim=rdim)
+            k8, sk = qa.dynamically_quantize_fp8(k, reduction_dim=rdim)
+            out[f"q8_{method}_compiled"] = bits8(q8)
+            out[f"k8_{method}_compiled"] = bits8(k8)
+            out[f"sq_{method}_compiled"] = sq.numpy().copy()
+            out[f"sk_{method}_compiled"] = sk.numpy().copy()
+            if with_eager:
+                q8e, sqe = qnn._dynamically_quantize_fp8(q, reduction_dim=rdim)
+                k8e, ske = qnn._dynamically_quantize_fp8(k, reduction_dim=rdim)
+                out[f"q8_{method}_eager"] = bits8(q8e)
+                out[f"k8_{method}_eager"] = bits8(k8e)
+                out[f"sq_{method}_eager"] = sqe.numpy().copy()
+                out[f"sk_{method}_eager"] = ske.numpy().copy()
+            for causal in (False, True):
+                if causal and Sq != Skv:
+                    continue  # reference tests skip this (tests/test_interface.py:32-33)
+                o1 = qops._fp8_attention_forward(q8, k8, v, sq, sk, is_causal=causal)
+                out[f"o1_{method}_{'causal' if causal else 'full'}"] = bits16(o1)
+        for causal in (False, True):
+            if causal and Sq != Skv:
+                continue
+            o16 = qops._attention_forward(q, k, v, is_causal=causal)
+            out[f"o16_{'causal' if causal else 'full'}"] = bits16(o16)
+        # CPU plumbing (BASELINE config 1): *_with_fallback degenerate to F.sdpa on CPU tensors
+        fb = qa.attn_func_with_fallback(q, k, v)
+        fb8 = qa.fp8_attn_func_with_fallback(q, k, v)
+        fbt = qa.fp8_token_wise_attn_func_with_fallback(q, k, v)
+        assert torch.equal(fb, fb8) and torch.equal(fb, fbt)
+        out["fallback_full"] = bits16(fb)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, {k_: v_.shape for k_, v_ in out.items() if k_ != "meta"})
+
+    # can_use_attention reason strings on CPU (interface contract, nn.py:209-211,282-307)
+    q = torch.randn(1, 2, 128, 64, dtype=torch.bfloat16)
+    ok, reason = qnn.can_use_attention(q, q, q)
+    with open(os.path.join(HERE, "can_use_attention_cpu.txt"), "w") as f:
+        f.write(f"{ok}\n{reason}\n")
+    print(ok, reason)
+
+
+if __name__ == "__main__":
+    main()
