@@ -1,0 +1,147 @@
+"""Pin the CPU oracle to the golden vectors generated from the reference (tests/golden/gen_golden.py).
+
+* quantiser restatement  == reference bytes and scales, bit-exact (both numerics, head/token, bf16/fp16)
+* torch restatement of the literal eager op == reference O1, bit-exact
+* fp64 C oracle (O2) within the reference's own bf16 rounding of O1 (SURVEY.md §8c two-oracle note)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import torch_ref
+from tests.conftest import GOLDEN, golden_files
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    B, H, Sq, Skv, D, is_bf16, seed = (int(x) for x in z["meta"])
+    return z, (B, H, Sq, Skv, D), (oracle.FMT_BF16 if is_bf16 else oracle.FMT_FP16)
+
+
+def _to_f32(bits, fmt):
+    return oracle.bf16_bits_to_f32(bits) if fmt == oracle.FMT_BF16 else oracle.fp16_bits_to_f32(bits)
+
+
+def _to_torch16(bits, fmt):
+    t = torch.from_numpy(bits.view(np.int16).copy())
+    return t.view(torch.bfloat16 if fmt == oracle.FMT_BF16 else torch.float16)
+
+
+@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("method", ["head", "token"])
+def test_quantiser_compiled_numerics_bit_exact(name, method):
+    z, _, fmt = _load(name)
+    for t in ("q", "k"):
+        got8, gots = oracle.quantize_fp8(z[t], fmt, method, oracle.FMT_E4M3, "compiled")
+        np.testing.assert_array_equal(gots.view(np.uint32), z[f"s{t}_{method}_compiled"].view(np.uint32))
+        np.testing.assert_array_equal(got8, z[f"{t}8_{method}_compiled"])
+
+
+@pytest.mark.parametrize("name", [f for f in golden_files() if f.startswith("c1_") and "_s0" in f])
+@pytest.mark.parametrize("method", ["head", "token"])
+def test_quantiser_eager_numerics_bit_exact(name, method):
+    z, _, fmt = _load(name)
+    for t in ("q", "k"):
+        got8, gots = oracle.quantize_fp8(z[t], fmt, method, oracle.FMT_E4M3, "eager")
+        np.testing.assert_array_equal(gots.view(np.uint32), z[f"s{t}_{method}_eager"].view(np.uint32))
+        np.testing.assert_array_equal(got8, z[f"{t}8_{method}_eager"])
+
+
+def test_fp8_codec_matches_torch_exhaustively():
+    # decode: all 256 bytes of both formats; encode: a dense sweep incl. ties, subnormals and the clamp edge
+    for fmt, tdt in ((oracle.FMT_E4M3, torch.float8_e4m3fn), (oracle.FMT_E5M2, torch.float8_e5m2)):
+        allb = np.arange(256, dtype=np.uint8)
+        ref = torch.from_numpy(allb.copy()).view(tdt).float().numpy()
+        got = oracle.fp8_to_f32(allb, fmt)
+        np.testing.assert_array_equal(np.isnan(ref), np.isnan(got))
+        np.testing.assert_array_equal(ref[~np.isnan(ref)], got[~np.isnan(got)])
+        qmax = oracle.FP8_MAX[fmt]
+        rng = np.random.default_rng(0)
+        xs = np.concatenate([
+            rng.standard_normal(20000).astype(np.float32) * 3,
+            (rng.standard_normal(20000) * qmax / 3).astype(np.float32).clip(-qmax, qmax),
+            np.ldexp(rng.uniform(1, 2, 20000), rng.integers(-20, 3, 20000)).astype(np.float32),
+            # exact midpoints between neighbouring fp8 values (ties -> even)
+            ((got[:-1][np.isfinite(got[:-1]) & np.isfinite(got[1:])] + got[1:][np.isfinite(got[:-1]) & np.isfinite(got[1:])]) / 2).astype(np.float32),
+            np.array([0.0, -0.0, qmax, -qmax], np.float32),
+        ])
+        xs = xs[np.abs(xs) <= qmax]
+        ref8 = torch.from_numpy(xs).to(tdt).view(torch.uint8).numpy()
+        got8 = oracle.f32_to_fp8(xs, fmt)
+        np.testing.assert_array_equal(ref8, got8)
+
+
+@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("method", ["head", "token"])
+def test_torch_port_of_eager_op_bit_exact_to_reference(name, method):
+    z, (B, H, Sq, Skv, D), fmt = _load(name)
+    q8 = torch.from_numpy(z[f"q8_{method}_compiled"].copy()).view(torch.float8_e4m3fn)
+    k8 = torch.from_numpy(z[f"k8_{method}_compiled"].copy()).view(torch.float8_e4m3fn)
+    sq = torch.from_numpy(z[f"sq_{method}_compiled"].copy())
+    sk = torch.from_numpy(z[f"sk_{method}_compiled"].copy())
+    v = _to_torch16(z["v"], fmt)
+    torch.set_num_threads(4)
+    for causal in (False, True):
+        key = f"o1_{method}_{'causal' if causal else 'full'}"
+        if key not in z:
+            continue
+        o = torch_ref.fp8_attention_forward_ref(q8, k8, v, sq, sk, is_causal=causal)
+        got = o.view(torch.int16).numpy().view(np.uint16)
+        # aten's CPU flash kernel is deterministic for a given thread partition; allow 1 bf16 ulp otherwise
+        a, b = _to_f32(got, fmt), _to_f32(z[key], fmt)
+        assert np.max(np.abs(a - b)) <= 2.0 ** -8 * max(1.0, float(np.max(np.abs(b)))), key
+
+
+@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("method", ["head", "token"])
+def test_c_oracle_within_reference_bf16_rounding(name, method):
+    z, (B, H, Sq, Skv, D), fmt = _load(name)
+    for causal in (False, True):
+        key = f"o1_{method}_{'causal' if causal else 'full'}"
+        if key not in z:
+            continue
+        o2 = oracle.attention_forward(z[f"q8_{method}_compiled"], z[f"k8_{method}_compiled"], z["v"],
+                                      oracle.FMT_E4M3, oracle.FMT_E4M3, fmt,
+                                      z[f"sq_{method}_compiled"], z[f"sk_{method}_compiled"], None,
+                                      scale_mode=method, causal=causal)
+        o1 = _to_f32(z[key], fmt)
+        err = np.max(np.abs(o2 - o1))
+        rmse = float(np.sqrt(np.mean((o2 - o1) ** 2)))
+        # O1 rounds scales, de-quantised q/k and the output to 16 bits (ops.py:76-91); measured <= 8e-3 for bf16
+        tol = 2.0 ** -6 if fmt == oracle.FMT_BF16 else 2.0 ** -8
+        assert err < tol and rmse < tol / 8, (key, err, rmse)
+
+
+@pytest.mark.parametrize("name", golden_files())
+def test_c_oracle_16bit_path_matches_reference_sdpa(name):
+    z, (B, H, Sq, Skv, D), fmt = _load(name)
+    for causal in (False, True):
+        key = f"o16_{'causal' if causal else 'full'}"
+        if key not in z:
+            continue
+        o = oracle.attention_forward(z["q"], z["k"], z["v"], fmt, fmt, fmt, causal=causal)
+        ref = _to_f32(z[key], fmt)
+        # aten's CPU kernel rounds P and the output to 16 bits: half an ulp of |ref| plus P-rounding noise
+        tol = 2.0 ** -6 if fmt == oracle.FMT_BF16 else 2.0 ** -9
+        assert np.max(np.abs(o - ref)) < tol and np.sqrt(np.mean((o - ref) ** 2)) < tol / 8
+    # CPU plumbing: *_with_fallback == F.sdpa (BASELINE config 1)
+    np.testing.assert_array_equal(z["fallback_full"], z["o16_full"])
+
+
+def test_oracle_lse_and_gqa_consistency():
+    rng = np.random.default_rng(1)
+    B, Hq, Hkv, S, D = 1, 4, 2, 40, 64
+    q = oracle.f32_to_bf16_bits(rng.standard_normal((B, Hq, S, D)).astype(np.float32))
+    k = oracle.f32_to_bf16_bits(rng.standard_normal((B, Hkv, S, D)).astype(np.float32))
+    v = oracle.f32_to_bf16_bits(rng.standard_normal((B, Hkv, S, D)).astype(np.float32))
+    o, lse = oracle.attention_forward(q, k, v, 2, 2, 2, causal=True, return_lse=True)
+    tq = torch.from_numpy(oracle.bf16_bits_to_f32(q)).double()
+    tk = torch.from_numpy(oracle.bf16_bits_to_f32(k)).double().repeat_interleave(2, dim=1)
+    tv = torch.from_numpy(oracle.bf16_bits_to_f32(v)).double().repeat_interleave(2, dim=1)
+    s = (tq @ tk.transpose(-1, -2)) / D ** 0.5
+    s = s.masked_fill(~torch.ones(S, S, dtype=torch.bool).tril(), float("-inf"))
+    np.testing.assert_allclose(lse, torch.logsumexp(s, -1).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(o, (torch.softmax(s, -1) @ tv).numpy(), rtol=1e-5, atol=1e-6)
