@@ -1,0 +1,124 @@
+/*
+ * qattn.h -- C ABI of libqattn_hip.so: MI355X (gfx950) FP8 fused attention forward + bf16/fp16->fp8 quant pre-pass.
+ *
+ * This is the drop-in boundary for the ONE hot path of WaveSpeedAI/QuantumAttention (reference @ 2025-02-22):
+ *
+ *   qattn_fp8_attention_forward  replaces  the pybind entry `attention_forward(q, k, v, scale_q, scale_k, causal)`
+ *                                          (src/quantum_attn/tk/attention.py:355-360, 688-702) behind the custom op
+ *                                          `quantum_attn::fp8_attention_forward` (src/quantum_attn/ops.py:98-121),
+ *                                          i.e. kernel `fwd_attend_ker<D,causal,..>` (tk/attention.py:97-349).
+ *   qattn_quant_fp8              replaces  `_dynamically_quantize_fp8` (src/quantum_attn/nn.py:14-19) as invoked by
+ *                                          `_fp8_attention_wrapper` (nn.py:410-418) / `dynamically_quantize_fp8`
+ *                                          (nn.py:22-42), which the reference leaves to Inductor-generated Triton.
+ *   qattn_pack_fp8               (no reference counterpart) re-lays a row-major fp8 K or V tensor into the MFMA
+ *                                          fragment layouts below; used when the caller hands pre-quantised q/k to the
+ *                                          op (ops.py:98-110 accepts float8 query/key with scale_q/scale_k).
+ *
+ * Conventions (same as the reference launcher, tk/attention.py:362-465, unless noted):
+ *   - plain C, no torch types; every pointer is a DEVICE pointer on the current HIP device;
+ *   - tensors are dense [B, H, S, D] ("row-major") unless a fragment layout is named;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls enqueue work and return
+ *     immediately -- no host synchronisation, no allocation, graph-capture safe;
+ *   - return 0 on success or a negative QATTN_ERR_* code; nothing is thrown; qattn_strerror() names the code.
+ *
+ * Fragment layouts (private to this library; produced by qattn_quant_fp8 / qattn_pack_fp8, consumed by the
+ * attention kernel; sequence length padded with zero bytes to a multiple of 64 keys, Sp = 64*ceil(S/64)):
+ *   QATTN_LAYOUT_KFRAG  per (b,h): chunks of 64 keys; chunk = [t:2][s:D/64][hh:2][half:2][key:32][16 bytes],
+ *                       byte j of a 16-byte piece = K[64*chunk + 32*t + key][64*s + 32*hh + 16*half + j].
+ *   QATTN_LAYOUT_VFRAG  per (b,h): chunks of 64 keys; chunk = [m:D/32][hh:2][half:2][d:32][16 bytes],
+ *                       byte 4*w+i of a piece = V[64*chunk + 32*half + 8*w + 4*hh + i][32*m + d]   (w,i in 0..3).
+ *   Both are D*Sp bytes per (b,h): the A operands of v_mfma_f32_32x32x64_f8f6f4 for S^T = K.Q^T and O^T = V^T.P^T,
+ *   conflict-free for ds_read_b128 and linear for LDS-DMA.
+ */
+#ifndef QATTN_H_
+#define QATTN_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QATTN_ABI_VERSION 1
+
+/* element formats */
+#define QATTN_FMT_E4M3 0 /* OCP float8_e4m3fn  (torch.float8_e4m3fn) */
+#define QATTN_FMT_E5M2 1 /* OCP float8_e5m2    (torch.float8_e5m2)   */
+#define QATTN_FMT_BF16 2
+#define QATTN_FMT_FP16 3
+
+/* scale granularity: head-wise = one fp32 per (b,h) [B,H]; token-wise = one per row [B,H,S]  (nn.py:410-414) */
+#define QATTN_SCALE_HEAD 0
+#define QATTN_SCALE_TOKEN 1
+
+/* memory layouts of an fp8 tensor */
+#define QATTN_LAYOUT_ROWMAJOR 0
+#define QATTN_LAYOUT_KFRAG 1
+#define QATTN_LAYOUT_VFRAG 2
+
+/* quantiser numerics: 0 = what the reference's compiled GPU path computes (fp32 scale,
+ * quotient rounded to the input dtype), 1 = the reference's eager arithmetic (everything in the input dtype). */
+#define QATTN_NUMERICS_COMPILED 0
+#define QATTN_NUMERICS_EAGER 1
+
+/* error codes */
+#define QATTN_OK 0
+#define QATTN_ERR_INVALID_ARG (-1)     /* NULL pointer, non-positive dimension, unknown enum */
+#define QATTN_ERR_UNSUPPORTED_DIM (-2) /* head_dim not in {64,128,256} (nn.py:45-49), or Hq % Hkv != 0 */
+#define QATTN_ERR_UNSUPPORTED_FMT (-3) /* format / layout combination not implemented */
+#define QATTN_ERR_WORKSPACE (-4)       /* workspace too small */
+#define QATTN_ERR_LAUNCH (-5)          /* HIP launch failed (hipGetLastError != hipSuccess) */
+#define QATTN_ERR_DEVICE (-6)          /* current device is not gfx950 */
+
+int qattn_abi_version(void);
+const char* qattn_strerror(int code);
+
+/* 0 if the current HIP device is gfx950 (MI355X), else QATTN_ERR_DEVICE.  Replaces the reference's
+ * `cuda_capability_compare("ge", 9, 0)` gate (src/quantum_attn/utils/checks.py:57-64, nn.py:214). */
+int qattn_check_device(void);
+
+/* bytes of an fp8 tensor [B,H,S,D] stored in `layout` (fragment layouts pad S to a multiple of 64). */
+size_t qattn_fp8_tensor_bytes(int layout, int B, int H, int S, int D);
+
+/* bytes of scratch qattn_quant_fp8 needs for these arguments (0 for token-wise). */
+size_t qattn_quant_workspace_bytes(int B, int H, int S, int D, int scale_mode);
+
+/*
+ * Quant pre-pass (nn.py:14-19): scale = clamp_min(amax|x| * (1/fmax), eps_f32); x8 = fp8(clamp(x/scale, +-fmax)).
+ *   x         [B,H,S,D] bf16 or fp16 (in_fmt), dense
+ *   x8        fp8 payload in `out_layout` (qattn_fp8_tensor_bytes bytes), out_fmt = E4M3 (reference) or E5M2
+ *   scale     fp32 [B,H] (QATTN_SCALE_HEAD, amax over S and D) or [B,H,S] (QATTN_SCALE_TOKEN, amax over D)
+ *   workspace device scratch of qattn_quant_workspace_bytes() bytes (may be NULL when that is 0)
+ * Bit-exact to the reference for numerics = QATTN_NUMERICS_COMPILED / _EAGER respectively.
+ */
+int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale, int B, int H, int S, int D, int out_fmt,
+                    int scale_mode, int numerics, int out_layout, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Re-lay a dense row-major fp8 tensor [B,H,S,D] into QATTN_LAYOUT_KFRAG or QATTN_LAYOUT_VFRAG (byte permutation). */
+int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S, int D, int out_layout, void* stream);
+
+/*
+ * FP8 fused attention forward:  O = softmax(sm_scale * (sq*Q8)(sk*K8)^T [+causal mask]) (sv*V8),  flash-style.
+ *   q8        [B,Hq,Sq,D]   fp8 (qk_fmt), row-major
+ *   k8        [B,Hkv,Skv,D] fp8 (qk_fmt), QATTN_LAYOUT_KFRAG
+ *   v8        [B,Hkv,Skv,D] fp8 (v_fmt),  QATTN_LAYOUT_VFRAG
+ *   out       [B,Hq,Sq,D]   bf16 or fp16 (out_fmt), row-major, written in full
+ *   lse       NULL, or fp32 [B,Hq,Sq]: natural-log-sum-exp of the scaled scores (the per-row vector the reference
+ *             defines but disables, tk/attention.py:333-346)
+ *   scale_q   fp32 [B,Hq] (head-wise) or [B,Hq,Sq] (token-wise);  scale_k likewise with Hkv,Skv
+ *   scale_v   fp32 [B,Hkv] or NULL (= 1.0)
+ *   sm_scale  softmax scale; <= 0 selects 1/sqrt(D) (the reference hard-wires it, tk/attention.py:208-210)
+ *   is_causal keep key j <= query i (aten top-left alignment; the reference requires Sq == Skv, tests/test_interface.py:32)
+ * Both GEMMs run on v_mfma_f32_32x32x64_f8f6f4; P is quantised to e4m3 (two-term hi+lo where few keys are visible).
+ * Accumulation, running max/sum and the softmax are fp32.
+ */
+int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, void* out, float* lse,
+                                const float* scale_q, const float* scale_k, const float* scale_v, int B, int Hq,
+                                int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt, int scale_mode,
+                                int is_causal, float sm_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QATTN_H_ */

@@ -1,0 +1,30 @@
+"""Flags, same mechanism as src/quantum_attn/config.py (env vars read at import + torch's config module so that
+`config.patch({...})` works, config.py:34-41).  Inductor/Triton-only flags of the reference are not reproduced."""
+import os  # noqa: C101
+import sys
+
+_save_config_ignore = set()
+
+
+class dynamo:
+    # kept for interface compatibility (config.py:14-17); this build never calls torch.compile on the hot path
+    dynamic = os.getenv("QUANTUM_ATTN_DYNAMIC") == "1"
+    mode = os.getenv("QUANTUM_ATTN_MODE", "default")
+
+
+class attention:
+    skip_supported_check = os.getenv("QUANTUM_ATTN_SKIP_SUPPORTED_CHECK") == "1"
+    force_eager_fallback = os.getenv("QUANTUM_ATTN_FORCE_EAGER_FALLBACK") == "1"
+
+    # replaces enable_tk_tma_kernel (config.py:30): gate of the hand-written gfx950 HIP kernel
+    enable_hip_kernel = os.getenv("QUANTUM_ATTN_ENABLE_HIP_KERNEL", "1") == "1"
+
+    # build extensions: fp8 format of the quantised operands ("e4m3" = reference, "e5m2") and quantiser numerics
+    fp8_format = os.getenv("QUANTUM_ATTN_FP8_FORMAT", "e4m3")
+    quant_numerics = os.getenv("QUANTUM_ATTN_QUANT_NUMERICS", "compiled")
+
+
+from torch.utils._config_module import install_config_module  # noqa: E402
+
+# adds patch, save_config, etc
+install_config_module(sys.modules[__name__])

@@ -1,0 +1,260 @@
+// qattn_quant.hip -- bf16/fp16 -> fp8 dynamic quantisation pre-pass and fp8 re-layout, gfx950.
+//
+// Replaces src/quantum_attn/nn.py:14-19 (`_dynamically_quantize_fp8`), which the reference leaves to
+// Inductor-generated Triton (nn.py:22-42, 410-418).  HBM-bound byte work: 16-byte coalesced loads, the fragment
+// permutation done in LDS, 16-byte linear stores.  Bit-exact to the reference in both of its numerics.
+#include "qattn_common.h"
+
+namespace qattn {
+
+// ---------------------------------------------------------------------------------------------------------
+// pass 1 (head-wise only): per-(b,h) abs-max.  |x| of bf16/fp16 is monotone in its low 15 bits, so the reduction
+// runs on packed 16-bit integers; NaN payloads (> inf as integers) propagate like torch's amax.
+// grid = (splits, groups), block = 256.  amax_bits[g] must be zero on entry (hipMemsetAsync in the launcher).
+// ---------------------------------------------------------------------------------------------------------
+template <int IN_FMT>
+__global__ __launch_bounds__(256) void amax_kernel(const uint4* __restrict__ x, unsigned* __restrict__ amax_bits,
+                                                   long vecs_per_group, int splits) {
+    const long g = blockIdx.y;
+    const uint4* xg = x + g * vecs_per_group;
+    const long per = (vecs_per_group + splits - 1) / splits;
+    const long beg = (long)blockIdx.x * per;
+    long end = beg + per;
+    if (end > vecs_per_group) end = vecs_per_group;
+    unsigned m0 = 0, m1 = 0;  // packed 2x u16 running max
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        uint4 v = xg[i];
+        unsigned a = v.x & 0x7fff7fffu, b = v.y & 0x7fff7fffu, c = v.z & 0x7fff7fffu, d = v.w & 0x7fff7fffu;
+        // packed u16 max
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        u16x2 pa, pb, pc, pd, p0, p1;
+        __builtin_memcpy(&pa, &a, 4); __builtin_memcpy(&pb, &b, 4); __builtin_memcpy(&pc, &c, 4); __builtin_memcpy(&pd, &d, 4);
+        __builtin_memcpy(&p0, &m0, 4); __builtin_memcpy(&p1, &m1, 4);
+        p0 = __builtin_elementwise_max(p0, __builtin_elementwise_max(pa, pb));
+        p1 = __builtin_elementwise_max(p1, __builtin_elementwise_max(pc, pd));
+        __builtin_memcpy(&m0, &p0, 4); __builtin_memcpy(&m1, &p1, 4);
+    }
+    unsigned m = max(max(m0 & 0xffffu, m0 >> 16), max(m1 & 0xffffu, m1 >> 16));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        const float f = load16f<IN_FMT>((unsigned short)m);  // |amax| as fp32 (exact)
+        atomicMax(amax_bits + g, __float_as_uint(f));         // non-negative floats order like their bit patterns
+    }
+}
+
+__device__ inline float make_scale(float amax, float inv_qmax, int numerics, int in_fmt) {
+    const float eps = 1.1920928955078125e-07f;  // torch.finfo(torch.float32).eps  (nn.py:15)
+    float s = amax * inv_qmax;
+    float e = eps;
+    if (numerics == QATTN_NUMERICS_EAGER) {
+        s = in_fmt == QATTN_FMT_BF16 ? round_bf16(s) : round_fp16(s);
+        e = in_fmt == QATTN_FMT_BF16 ? round_bf16(eps) : round_fp16(eps);
+    }
+    if (!(s >= e)) s = (s != s) ? s : e;  // clamp_min keeps NaN
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pass 2: quantise one tile of 64 rows x D and emit it in the requested layout.
+// grid = (ceil(S/64), B*H), block = 256.  Each thread owns D/32 vectors of 8 consecutive elements of one row.
+// ---------------------------------------------------------------------------------------------------------
+template <int D, int IN_FMT, int OUT_FMT, int LAYOUT, bool TOKEN>
+__global__ __launch_bounds__(256) void quant_tile_kernel(const uint4* __restrict__ x, uint4* __restrict__ out,
+                                                         float* __restrict__ scale_out,
+                                                         const unsigned* __restrict__ amax_bits, int S, int numerics) {
+    constexpr int VPR = D / 8;            // 16-byte input vectors per row
+    constexpr int ITERS = 64 * VPR / 256; // vectors per thread
+    __shared__ __attribute__((aligned(16))) unsigned char img[64 * D];
+    const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int row0 = tile * 64;
+    const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
+    const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
+    float scale = 1.0f;
+    if (!TOKEN) {
+        scale = make_scale(__uint_as_float(amax_bits[g]), inv_qmax, numerics, IN_FMT);
+        if (tile == 0 && tid == 0) scale_out[g] = scale;
+    }
+    const uint4* xg = x + (long)g * S * VPR;
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int vec = it * 256 + tid;
+        const int r = vec / VPR, dv = vec % VPR;
+        const int row = row0 + r;
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (row < S) raw = xg[(long)row * VPR + dv];
+        unsigned short e[8];
+        __builtin_memcpy(e, &raw, 16);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] = load16f<IN_FMT>(e[j]);
+        if (TOKEN) {
+            float a = 0.0f;
+            bool nan = false;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a = fmaxf(a, fabsf(f[j])); nan |= (f[j] != f[j]); }
+            unsigned ab = nan ? 0x7fc00000u : __float_as_uint(a);
+#pragma unroll
+            for (int off = VPR / 2; off > 0; off >>= 1) ab = max(ab, (unsigned)__shfl_xor((int)ab, off));
+            scale = make_scale(__uint_as_float(ab), inv_qmax, numerics, IN_FMT);
+            if (dv == 0 && row < S) scale_out[(long)g * S + row] = scale;
+        }
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float t = round16<IN_FMT>(f[j] / scale);  // IEEE fp32 divide, then the reference's rounding to the input dtype
+            t = t > qmax ? qmax : t;
+            t = t < -qmax ? -qmax : t;
+            q[j] = t;
+        }
+        const int lo = cvt4_fp8<OUT_FMT>(q[0], q[1], q[2], q[3]);
+        const int hi = cvt4_fp8<OUT_FMT>(q[4], q[5], q[6], q[7]);
+        const int d0 = dv * 8;
+        if (LAYOUT == QATTN_LAYOUT_ROWMAJOR) {
+            *reinterpret_cast<int2*>(img + r * D + d0) = make_int2(lo, hi);
+        } else if (LAYOUT == QATTN_LAYOUT_KFRAG) {
+            *reinterpret_cast<int2*>(img + kfrag_offset<D>(r, d0)) = make_int2(lo, hi);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                img[vfrag_offset<D>(r, d0 + j)] = (unsigned char)(lo >> (8 * j));
+                img[vfrag_offset<D>(r, d0 + 4 + j)] = (unsigned char)(hi >> (8 * j));
+            }
+        }
+    }
+    __syncthreads();
+    // linear write-out of the 64*D-byte image
+    constexpr int OUT_VECS = 64 * D / 16;
+    if (LAYOUT == QATTN_LAYOUT_ROWMAJOR) {
+        uint4* og = out + (long)g * S * (D / 16) + (long)row0 * (D / 16);
+        const int valid = (S - row0 < 64 ? S - row0 : 64) * (D / 16);
+        for (int i = tid; i < valid; i += 256) og[i] = reinterpret_cast<const uint4*>(img)[i];
+    } else {
+        const long Sp = (long)((S + 63) / 64) * 64;
+        uint4* og = out + ((long)g * Sp + row0) * (D / 16);
+        for (int i = tid; i < OUT_VECS; i += 256) og[i] = reinterpret_cast<const uint4*>(img)[i];
+    }
+}
+
+// fp8 row-major -> fragment layout (pure byte permutation).  grid = (ceil(S/64), B*H), block = 256.
+template <int D, int LAYOUT>
+__global__ __launch_bounds__(256) void pack_tile_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int S) {
+    constexpr int VPR = D / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char img[64 * D];
+    const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, row0 = tile * 64;
+    const uint4* xg = x + (long)g * S * VPR;
+    for (int vec = tid; vec < 64 * VPR; vec += 256) {
+        const int r = vec / VPR, dv = vec % VPR, row = row0 + r;
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (row < S) raw = xg[(long)row * VPR + dv];
+        if (LAYOUT == QATTN_LAYOUT_KFRAG) {
+            *reinterpret_cast<uint4*>(img + kfrag_offset<D>(r, dv * 16)) = raw;
+        } else {
+            unsigned char b[16];
+            __builtin_memcpy(b, &raw, 16);
+#pragma unroll
+            for (int j = 0; j < 16; j++) img[vfrag_offset<D>(r, dv * 16 + j)] = b[j];
+        }
+    }
+    __syncthreads();
+    const long Sp = (long)((S + 63) / 64) * 64;
+    uint4* og = out + ((long)g * Sp + row0) * (D / 16);
+    for (int i = tid; i < 64 * D / 16; i += 256) og[i] = reinterpret_cast<const uint4*>(img)[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------------------
+template <int D, int IN_FMT, int OUT_FMT>
+static int launch_quant_dl(const void* x, void* x8, float* scale, int G, int S, int scale_mode, int numerics,
+                           int layout, const unsigned* amax, hipStream_t st) {
+    dim3 grid((S + 63) / 64, G), block(256);
+    const uint4* xi = (const uint4*)x;
+    uint4* xo = (uint4*)x8;
+#define QL(LAY, TOK) hipLaunchKernelGGL((quant_tile_kernel<D, IN_FMT, OUT_FMT, LAY, TOK>), grid, block, 0, st, xi, xo, scale, amax, S, numerics)
+    const bool tok = scale_mode == QATTN_SCALE_TOKEN;
+    if (layout == QATTN_LAYOUT_ROWMAJOR) { if (tok) QL(QATTN_LAYOUT_ROWMAJOR, true); else QL(QATTN_LAYOUT_ROWMAJOR, false); }
+    else if (layout == QATTN_LAYOUT_KFRAG) { if (tok) QL(QATTN_LAYOUT_KFRAG, true); else QL(QATTN_LAYOUT_KFRAG, false); }
+    else if (layout == QATTN_LAYOUT_VFRAG) { if (tok) QL(QATTN_LAYOUT_VFRAG, true); else QL(QATTN_LAYOUT_VFRAG, false); }
+    else return QATTN_ERR_INVALID_ARG;
+#undef QL
+    return QATTN_OK;
+}
+
+template <int D>
+static int launch_quant_d(const void* x, int in_fmt, void* x8, float* scale, int G, int S, int out_fmt, int scale_mode,
+                          int numerics, int layout, const unsigned* amax, hipStream_t st) {
+    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E4M3) return launch_quant_dl<D, QATTN_FMT_BF16, QATTN_FMT_E4M3>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
+    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E5M2) return launch_quant_dl<D, QATTN_FMT_BF16, QATTN_FMT_E5M2>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
+    if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E4M3) return launch_quant_dl<D, QATTN_FMT_FP16, QATTN_FMT_E4M3>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
+    if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E5M2) return launch_quant_dl<D, QATTN_FMT_FP16, QATTN_FMT_E5M2>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
+    return QATTN_ERR_UNSUPPORTED_FMT;
+}
+
+}  // namespace qattn
+
+using namespace qattn;
+
+extern "C" size_t qattn_fp8_tensor_bytes(int layout, int B, int H, int S, int D) {
+    if (B <= 0 || H <= 0 || S <= 0 || D <= 0) return 0;
+    const size_t Sp = layout == QATTN_LAYOUT_ROWMAJOR ? (size_t)S : (size_t)((S + 63) / 64) * 64;
+    return (size_t)B * H * Sp * D;
+}
+
+extern "C" size_t qattn_quant_workspace_bytes(int B, int H, int S, int D, int scale_mode) {
+    (void)S; (void)D;
+    if (B <= 0 || H <= 0) return 0;
+    return scale_mode == QATTN_SCALE_HEAD ? (size_t)B * H * sizeof(unsigned) : 0;
+}
+
+extern "C" int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale, int B, int H, int S, int D,
+                               int out_fmt, int scale_mode, int numerics, int out_layout, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!x || !x8 || !scale || B <= 0 || H <= 0 || S <= 0) return QATTN_ERR_INVALID_ARG;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
+    if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (out_fmt != QATTN_FMT_E4M3 && out_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = B * H;
+    unsigned* amax = nullptr;
+    if (scale_mode == QATTN_SCALE_HEAD) {
+        if (!workspace || workspace_bytes < (size_t)G * sizeof(unsigned)) return QATTN_ERR_WORKSPACE;
+        amax = (unsigned*)workspace;
+        if (hipMemsetAsync(amax, 0, (size_t)G * sizeof(unsigned), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+        const long vecs = (long)S * D / 8;
+        int splits = (int)((vecs + 4095) / 4096);  // >= 16 vectors per thread per split
+        if (splits < 1) splits = 1;
+        if (splits > 64) splits = 64;
+        dim3 grid(splits, G), block(256);
+        if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_kernel<QATTN_FMT_BF16>), grid, block, 0, st, (const uint4*)x, amax, vecs, splits);
+        else hipLaunchKernelGGL((amax_kernel<QATTN_FMT_FP16>), grid, block, 0, st, (const uint4*)x, amax, vecs, splits);
+    }
+    int rc;
+    if (D == 64) rc = launch_quant_d<64>(x, in_fmt, x8, scale, G, S, out_fmt, scale_mode, numerics, out_layout, amax, st);
+    else if (D == 128) rc = launch_quant_d<128>(x, in_fmt, x8, scale, G, S, out_fmt, scale_mode, numerics, out_layout, amax, st);
+    else rc = launch_quant_d<256>(x, in_fmt, x8, scale, G, S, out_fmt, scale_mode, numerics, out_layout, amax, st);
+    if (rc != QATTN_OK) return rc;
+    return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
+}
+
+extern "C" int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S, int D, int out_layout,
+                              void* stream) {
+    if (!x8_rowmajor || !x8_packed || B <= 0 || H <= 0 || S <= 0) return QATTN_ERR_INVALID_ARG;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (out_layout != QATTN_LAYOUT_KFRAG && out_layout != QATTN_LAYOUT_VFRAG) return QATTN_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((S + 63) / 64, B * H), block(256);
+    const uint4* xi = (const uint4*)x8_rowmajor;
+    uint4* xo = (uint4*)x8_packed;
+#define PK(DD, LAY) hipLaunchKernelGGL((pack_tile_kernel<DD, LAY>), grid, block, 0, st, xi, xo, S)
+    if (out_layout == QATTN_LAYOUT_KFRAG) { if (D == 64) PK(64, QATTN_LAYOUT_KFRAG); else if (D == 128) PK(128, QATTN_LAYOUT_KFRAG); else PK(256, QATTN_LAYOUT_KFRAG); }
+    else { if (D == 64) PK(64, QATTN_LAYOUT_VFRAG); else if (D == 128) PK(128, QATTN_LAYOUT_VFRAG); else PK(256, QATTN_LAYOUT_VFRAG); }
+#undef PK
+    return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
+}

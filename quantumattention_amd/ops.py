@@ -1,0 +1,113 @@
+"""Operator boundary.  Mirrors src/quantum_attn/ops.py: two torch custom ops with the reference's schemas
+(ops.py:32-42, 98-110), registered for device type "cuda" (= HIP on PyTorch-ROCm) with fake impls so that
+callers under torch.compile keep working.  The namespace is `quantumattention_amd` rather than `quantum_attn`
+so the reference can be imported beside this package in one process (torch.library.define would collide).
+
+Unlike the reference -- whose eager impl is aten SDPA on de-quantised inputs and whose real kernel is reached
+only through an Inductor lowering (inductor/kernels/attention.py:1037-1065) -- the implementation here calls
+the hand-written gfx950 kernels through the C ABI directly.  There is no eager/CPU fallback at this level.
+"""
+from typing import Optional
+
+import torch
+
+from . import _native
+
+_custom_op = torch.library.custom_op
+_register_fake = torch.library.register_fake
+
+
+def _out_like(query: torch.Tensor, value: torch.Tensor) -> torch.Tensor:
+    return torch.empty(query.shape[:-1] + (value.shape[-1],), dtype=value.dtype, device=value.device)
+
+
+def _check_op_args(attn_mask, dropout_p, scale):
+    # same asserts as tk_fp8_attention_forward_kernel (inductor/kernels/attention.py:55-73)
+    if attn_mask is not None:
+        raise RuntimeError("attn_mask is not supported by the gfx950 attention kernel")
+    if dropout_p != 0.0:
+        raise RuntimeError("dropout_p must be 0.0 for the gfx950 attention kernel")
+
+
+@_custom_op("quantumattention_amd::fp8_attention_forward", mutates_args=(), device_types=("cuda",))
+def fp8_attention_forward(
+    query: torch.Tensor,
+    key: torch.Tensor,
+    value: torch.Tensor,
+    scale_q: Optional[torch.Tensor] = None,
+    scale_k: Optional[torch.Tensor] = None,
+    attn_mask: Optional[torch.Tensor] = None,
+    dropout_p: float = 0.0,
+    is_causal: bool = False,
+    *,
+    scale: Optional[float] = None,
+) -> torch.Tensor:
+    """query/key: fp8 (e4m3fn or e5m2) [B,H,S,D] row-major with fp32 scales [B,H] (head-wise) or [B,H,S]
+    (token-wise); value: bf16/fp16.  Same contract as quantum_attn::fp8_attention_forward (ops.py:98-121)."""
+    _check_op_args(attn_mask, dropout_p, scale)
+    if scale_q is None or scale_k is None:
+        raise RuntimeError("fp8_attention_forward needs scale_q and scale_k")
+    if query.dtype not in (torch.float8_e4m3fn, torch.float8_e5m2) or key.dtype != query.dtype:
+        raise RuntimeError(f"query/key must share an fp8 dtype, got {query.dtype} and {key.dtype}")
+    scaling = "head-wise" if scale_q.dim() == query.dim() - 2 else "token-wise"
+    B, Hkv, Skv, D = key.shape
+    k_frag = _native.pack_fp8(key, _native.LAYOUT_KFRAG)
+    v_frag, scale_v = _native.quant_fp8(value, scaling="head-wise", fp8_dtype=query.dtype,
+                                        layout=_native.LAYOUT_VFRAG)
+    return _native.fp8_attention_forward(
+        query, k_frag, v_frag, scale_q, scale_k, scale_v, Hkv=Hkv, Skv=Skv, out_dtype=value.dtype,
+        is_causal=is_causal, scaling=scaling, sm_scale=0.0 if scale is None else float(scale))
+
+
+@_register_fake("quantumattention_amd::fp8_attention_forward")
+def _(query, key, value, scale_q=None, scale_k=None, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None):
+    return _out_like(query, value)
+
+
+@_custom_op("quantumattention_amd::fp8_quant_attention_forward", mutates_args=(), device_types=("cuda",))
+def fp8_quant_attention_forward(
+    query: torch.Tensor,
+    key: torch.Tensor,
+    value: torch.Tensor,
+    is_causal: bool = False,
+    scaling_method: str = "head-wise",
+    fp8_format: str = "e4m3",
+    numerics: str = "compiled",
+    *,
+    scale: Optional[float] = None,
+) -> torch.Tensor:
+    """Fused entry for 16-bit inputs: the quant pre-pass (nn.py:410-418) writes K and V straight into the MFMA
+    fragment layouts, then the attention kernel runs -- what `_fp8_attention_wrapper` (nn.py:394-430) does in the
+    reference through Inductor, without the intermediate row-major K copy."""
+    fp8_dtype = _native.FP8_DTYPE[fp8_format]
+    q8, sq = _native.quant_fp8(query, scaling=scaling_method, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_ROWMAJOR,
+                               numerics=numerics)
+    k_frag, sk = _native.quant_fp8(key, scaling=scaling_method, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_KFRAG,
+                                   numerics=numerics)
+    v_frag, sv = _native.quant_fp8(value, scaling="head-wise", fp8_dtype=fp8_dtype, layout=_native.LAYOUT_VFRAG,
+                                   numerics=numerics)
+    return _native.fp8_attention_forward(
+        q8, k_frag, v_frag, sq, sk, sv, Hkv=key.shape[1], Skv=key.shape[2], out_dtype=value.dtype,
+        is_causal=is_causal, scaling=scaling_method, sm_scale=0.0 if scale is None else float(scale))
+
+
+@_register_fake("quantumattention_amd::fp8_quant_attention_forward")
+def _(query, key, value, is_causal=False, scaling_method="head-wise", fp8_format="e4m3", numerics="compiled", *,
+      scale=None):
+    return _out_like(query, value)
+
+
+@_custom_op("quantumattention_amd::dynamically_quantize_fp8", mutates_args=(), device_types=("cuda",))
+def dynamically_quantize_fp8_op(t: torch.Tensor, token_wise: bool, fp8_format: str = "e4m3",
+                                numerics: str = "compiled") -> tuple[torch.Tensor, torch.Tensor]:
+    """HIP quant pre-pass for a 4-D [B,H,S,D] tensor (nn.py:14-19): head-wise (dims 2,3) or token-wise (dim 3)."""
+    return _native.quant_fp8(t, scaling="token-wise" if token_wise else "head-wise",
+                             fp8_dtype=_native.FP8_DTYPE[fp8_format], layout=_native.LAYOUT_ROWMAJOR,
+                             numerics=numerics)
+
+
+@_register_fake("quantumattention_amd::dynamically_quantize_fp8")
+def _(t, token_wise, fp8_format="e4m3", numerics="compiled"):
+    q = torch.empty(t.shape, dtype=_native.FP8_DTYPE[fp8_format], device=t.device)
+    s = torch.empty(t.shape[:3] if token_wise else t.shape[:2], dtype=torch.float32, device=t.device)
+    return q, s

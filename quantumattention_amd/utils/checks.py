@@ -1,0 +1,40 @@
+"""Device / version predicates.  Mirrors src/quantum_attn/utils/checks.py, with the reference's NVIDIA gate
+(`is_nvidia_cuda` + `cuda_capability_compare("ge", 9, 0)`, checks.py:57-64, nn.py:214) replaced by a gfx950 gate."""
+import functools
+import importlib
+
+import torch
+from packaging import version
+
+
+@torch.compiler.assume_constant_result
+def get_constant_attr(module, attr):
+    obj = importlib.import_module(module)
+    for a in attr.split("."):
+        obj = getattr(obj, a)
+    return obj
+
+
+def torch_version_compare(op, v):
+    return getattr(version.parse(torch.__version__).release, f"__{op}__")(version.parse(v).release)
+
+
+def is_amd_rocm() -> bool:
+    return torch.version.hip is not None and torch.cuda.is_available()
+
+
+@functools.lru_cache(maxsize=None)
+def _arch_name(index: int) -> str:
+    return torch.cuda.get_device_properties(index).gcnArchName
+
+
+def is_gfx950(device=None) -> bool:
+    """True when `device` is an MI355X-class (gfx950 / CDNA4) GPU under PyTorch-ROCm."""
+    if not is_amd_rocm():
+        return False
+    if device is None:
+        index = torch.cuda.current_device()
+    else:
+        device = torch.device(device)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+    return "gfx950" in _arch_name(index)

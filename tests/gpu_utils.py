@@ -1,0 +1,57 @@
+"""Helpers shared by the -m gpu parity tests: numpy <-> torch bit views, fragment-layout inverse maps, and the
+oracle call that mirrors one HIP attention launch (same quantised q/k/v, fp64 math)."""
+import numpy as np
+import torch
+
+import oracle
+from quantumattention_amd import _native
+
+FMT = {"e4m3": oracle.FMT_E4M3, "e5m2": oracle.FMT_E5M2}
+TDT = {"e4m3": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}
+
+
+def bits16(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def bits8(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().view(torch.uint8).numpy()
+
+
+def from_bits16(b: np.ndarray, dtype) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(b).view(np.int16).copy()).view(dtype)
+
+
+def fmt16(dtype) -> int:
+    return oracle.FMT_BF16 if dtype == torch.bfloat16 else oracle.FMT_FP16
+
+
+def out_to_f32(t: torch.Tensor) -> np.ndarray:
+    return t.detach().float().cpu().numpy()
+
+
+def unpack_frag(buf: np.ndarray, layout: int, B: int, H: int, S: int, D: int) -> np.ndarray:
+    """Invert QATTN_LAYOUT_KFRAG / _VFRAG (include/qattn.h) -> row-major [B,H,Sp,D] (Sp = S padded to 64)."""
+    Sp = (S + 63) // 64 * 64
+    x = np.asarray(buf, np.uint8).reshape(B, H, Sp // 64, 64 * D)
+    key = np.arange(64)[:, None]
+    d = np.arange(D)[None, :]
+    if layout == _native.LAYOUT_KFRAG:
+        off = (((key >> 5) * (D // 64) + (d >> 6)) << 11) + (((d >> 5) & 1) << 10) + (((d >> 4) & 1) << 9) + ((key & 31) << 4) + (d & 15)
+    else:
+        half, w, hh, i = key >> 5, (key >> 3) & 3, (key >> 2) & 1, key & 3
+        off = ((d >> 5) << 11) + (hh << 10) + (half << 9) + ((d & 31) << 4) + (w << 2) + i
+    return x[..., off].reshape(B, H, Sp, D)
+
+
+def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfloat16, scaling="head", causal=False,
+                        sm_scale=0.0, return_lse=False):
+    """O3 of SURVEY.md §8c: fp64 SDPA on the same quantised q, k AND the build's quantised v."""
+    v8, sv = oracle.quantize_fp8(v16b, fmt16(v_dtype), "head", FMT[fp8], "compiled")
+    return oracle.attention_forward(q8b, k8b, v8, FMT[fp8], FMT[fp8], FMT[fp8], sq, sk, sv, scale_mode=scaling,
+                                    causal=causal, sm_scale=sm_scale, return_lse=return_lse)
+
+
+def err_stats(got: np.ndarray, ref: np.ndarray):
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    return float(d.max()), float(np.sqrt((d ** 2).mean()))

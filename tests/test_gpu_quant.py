@@ -1,0 +1,75 @@
+"""-m gpu: the HIP quant pre-pass and the fragment re-layout, bit-exact against the oracle and the golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from quantumattention_amd import _native
+from tests.conftest import GOLDEN, golden_files
+from tests.gpu_utils import FMT, TDT, bits16, bits8, fmt16, from_bits16, unpack_frag
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("scaling", ["head-wise", "token-wise"])
+def test_quant_matches_reference_golden_bit_exact(name, scaling):
+    z = np.load(os.path.join(GOLDEN, name))
+    dtype = torch.bfloat16 if int(z["meta"][5]) else torch.float16
+    m = "head" if scaling == "head-wise" else "token"
+    for t in ("q", "k"):
+        x = from_bits16(z[t], dtype).cuda()
+        for numerics in ("compiled", "eager"):
+            if f"{t}8_{m}_{numerics}" not in z:
+                continue
+            x8, s = _native.quant_fp8(x, scaling=scaling, numerics=numerics)
+            np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), z[f"s{t}_{m}_{numerics}"].view(np.uint32))
+            np.testing.assert_array_equal(bits8(x8), z[f"{t}8_{m}_{numerics}"])
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 64, 64), (2, 3, 200, 128), (1, 2, 1000, 256), (1, 1, 4096, 128), (1, 2, 37, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fp8", ["e4m3", "e5m2"])
+@pytest.mark.parametrize("scaling", ["head-wise", "token-wise"])
+def test_quant_matches_oracle_bit_exact_all_layouts(shape, dtype, fp8, scaling):
+    torch.manual_seed(hash((shape, fp8, scaling)) % 1000)
+    B, H, S, D = shape
+    x = (torch.randn(shape, dtype=torch.float32) * torch.rand(B, H, 1, 1) * 3).to(dtype)
+    x[0, 0, 0, :8] = 0.0
+    if S > 5:
+        x[0, -1, 5, :] = 0.0  # an all-zero row: token-wise scale clamps to eps
+    ref8, refs = oracle.quantize_fp8(bits16(x), fmt16(dtype), "head" if scaling == "head-wise" else "token", FMT[fp8], "compiled")
+    xg = x.cuda()
+    for layout in (_native.LAYOUT_ROWMAJOR, _native.LAYOUT_KFRAG, _native.LAYOUT_VFRAG):
+        x8, s = _native.quant_fp8(xg, scaling=scaling, fp8_dtype=TDT[fp8], layout=layout)
+        np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), refs.view(np.uint32))
+        got = bits8(x8)
+        if layout != _native.LAYOUT_ROWMAJOR:
+            full = unpack_frag(got, layout, B, H, S, D)
+            assert not full[:, :, S:, :].any(), "padding rows must be zero"
+            got = full[:, :, :S, :]
+        np.testing.assert_array_equal(got, ref8)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 64, 64), (2, 2, 200, 128), (1, 1, 130, 256)])
+@pytest.mark.parametrize("layout", [_native.LAYOUT_KFRAG, _native.LAYOUT_VFRAG])
+def test_pack_is_the_documented_permutation(shape, layout):
+    B, H, S, D = shape
+    x = torch.randint(0, 256, shape, dtype=torch.uint8)
+    packed = _native.pack_fp8(x.cuda().view(torch.float8_e4m3fn), layout)
+    full = unpack_frag(bits8(packed), layout, B, H, S, D)
+    np.testing.assert_array_equal(full[:, :, :S, :], x.numpy())
+    assert not full[:, :, S:, :].any()
+
+
+def test_quant_eager_numerics_and_constant_tensor():
+    x = torch.full((1, 1, 64, 64), 0.5, dtype=torch.bfloat16)
+    x8, s = _native.quant_fp8(x.cuda(), numerics="eager")
+    r8, rs = oracle.quantize_fp8(bits16(x), oracle.FMT_BF16, "head", oracle.FMT_E4M3, "eager")
+    np.testing.assert_array_equal(bits8(x8), r8)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+    z = torch.zeros((1, 1, 64, 64), dtype=torch.float16)
+    x8, s = _native.quant_fp8(z.cuda())
+    assert not bits8(x8).any() and float(s[0, 0]) == float(np.float32(1.1920928955078125e-07))
