@@ -1,0 +1,71 @@
+// qattn_api.hip -- C-ABI entry points of libqattn_hip.so that are not in qattn_quant.hip (include/qattn.h).
+#include <cstdlib>
+#include <cstring>
+
+#include "qattn_attn.h"
+
+using namespace qattn;
+
+// Development switch: QATTN_KERNEL_VARIANT=1 selects the first (non-pipelined) kernel structure for A/B runs.
+static int kernel_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("QATTN_KERNEL_VARIANT");
+        v = e ? atoi(e) : 2;
+    }
+    return v;
+}
+
+extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, void* out, float* lse,
+                                           const float* scale_q, const float* scale_k, const float* scale_v, int B,
+                                           int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt,
+                                           int scale_mode, int is_causal, float sm_scale, void* stream) {
+    // argument checks mirror the reference launcher's TORCH_CHECKs (tk/attention.py:362-415)
+    if (!q8 || !k8 || !v8 || !out || !scale_q || !scale_k) return QATTN_ERR_INVALID_ARG;
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;  // nn.py:45-49
+    if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;                    // tk/attention.py:398-399
+    if (qk_fmt != QATTN_FMT_E4M3 && qk_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (v_fmt != qk_fmt) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (out_fmt != QATTN_FMT_BF16 && out_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    AttnParams p;
+    p.q = (const unsigned char*)q8; p.k = (const unsigned char*)k8; p.v = (const unsigned char*)v8;
+    p.out = out; p.lse = lse; p.sq = scale_q; p.sk = scale_k; p.sv = scale_v;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
+    p.nqb = ceil_div(Sq, kQPerWG);
+    p.nchunks = ceil_div(Skv, 64);
+    p.out_fmt = out_fmt;
+    p.xcd_remap = ((B * Hq) % 8 == 0) ? 1 : 0;
+    const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
+    p.sm_log2e = sm * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (D != 128 || kernel_variant() == 1) rc = launch_attn_v1(p, D, qk_fmt, is_causal, scale_mode, st);
+    else rc = launch_attn_v2(p, D, qk_fmt, is_causal, scale_mode, st);
+    if (rc != QATTN_OK) return rc;
+    return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
+}
+
+extern "C" int qattn_abi_version(void) { return QATTN_ABI_VERSION; }
+
+extern "C" const char* qattn_strerror(int code) {
+    switch (code) {
+        case QATTN_OK: return "ok";
+        case QATTN_ERR_INVALID_ARG: return "invalid argument (null pointer, non-positive dimension or unknown enum)";
+        case QATTN_ERR_UNSUPPORTED_DIM: return "unsupported head dimension (need 64, 128 or 256) or Hq not divisible by Hkv";
+        case QATTN_ERR_UNSUPPORTED_FMT: return "unsupported element format / layout combination";
+        case QATTN_ERR_WORKSPACE: return "workspace missing or too small";
+        case QATTN_ERR_LAUNCH: return "HIP kernel launch failed";
+        case QATTN_ERR_DEVICE: return "current HIP device is not gfx950 (MI355X)";
+        default: return "unknown qattn error code";
+    }
+}
+
+extern "C" int qattn_check_device(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return QATTN_ERR_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return QATTN_ERR_DEVICE;
+    return strstr(prop.gcnArchName, "gfx950") ? QATTN_OK : QATTN_ERR_DEVICE;
+}

@@ -1,4 +1,5 @@
-// qattn_attn.hip -- FP8 fused attention forward for gfx950 (MI355X / CDNA4).
+// qattn_attn_v1.hip -- FP8 fused attention forward, first (non-pipelined) structure.  Kept as the D=256 path and
+// as the A/B baseline for qattn_attn_v2.hip (select with QATTN_KERNEL_VARIANT=1).
 //
 // Replaces fwd_attend_ker<D,causal,..> + its launcher (src/quantum_attn/tk/attention.py:97-349, 355-647) behind the
 // op quantum_attn::fp8_attention_forward (src/quantum_attn/ops.py:98-121).  Designed for CDNA4, not translated:
@@ -16,51 +17,15 @@
 //  * online softmax in the exp2 domain with a deferred-max rescale (O and l are only rescaled when some row's
 //    max grew by more than kRescaleThr); P is scaled by 2^kPShift before the e4m3 conversion to keep small
 //    probabilities out of the subnormal range; where few keys are visible P is split hi+lo (two fp8 terms).
-#include "qattn_common.h"
+#include "qattn_attn.h"
 
 namespace qattn {
 
-constexpr int kWaves = 8;
-constexpr int kThreads = kWaves * 64;
-constexpr int kQPerWave = 32;
-constexpr int kQPerWG = kWaves * kQPerWave;  // 256
 constexpr int kStages = 3;
-constexpr float kPShift = 5.0f;       // P' = P * 2^5
-constexpr float kRescaleThr = 3.0f;   // log2 units; P' <= 2^(5+3) = 256 < 448 (e4m3 max)
-constexpr int kTwoTermKeys = 1024;    // rows that see fewer keys than this use hi+lo fp8 P
 
-struct AttnParams {
-    const unsigned char* q;
-    const unsigned char* k;
-    const unsigned char* v;
-    void* out;
-    float* lse;
-    const float* sq;
-    const float* sk;
-    const float* sv;
-    int B, Hq, Hkv, Sq, Skv;
-    int nqb;        // query blocks per head
-    int nchunks;    // 64-key chunks per head
-    int out_fmt;
-    int xcd_remap;  // 1: heads grouped per XCD
-    float sm_log2e; // sm_scale * log2(e)
-};
 
-template <int CBSZ, int BLGP>
-__device__ inline v16f mfma_f8(v8i a, v8i b, v16f c) {
-    // scale operands 0 -> the unscaled v_mfma_f32_32x32x64_f8f6f4 (implicit scale 1.0)
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, CBSZ, BLGP, 0, 0, 0, 0);
-}
 
-__device__ inline v8i lds_read_frag(const unsigned char* base) {
-    // two ds_read_b128: pieces [half=0] and [half=1] are 512 bytes apart
-    v4i lo = *reinterpret_cast<const v4i*>(base);
-    v4i hi = *reinterpret_cast<const v4i*>(base + 512);
-    v8i r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
+
 
 template <int D>
 __device__ inline void stage_chunk(const unsigned char* kg, const unsigned char* vg, unsigned char* lds_stage, int wave, int lane) {
@@ -77,18 +42,10 @@ __device__ inline void stage_chunk(const unsigned char* kg, const unsigned char*
     }
 }
 
-template <int N>
-__device__ inline void wait_vmcnt() {
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 
 // QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
 template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v1(const AttnParams p) {
     constexpr int CH = 64 * D;          // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;       // K chunk + V chunk
     constexpr int KS = D / 64;          // QK^T k-steps
@@ -327,15 +284,15 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnParams 
 }
 
 template <int D, int FMT, bool CAUSAL>
-static int launch_attn(const AttnParams& p, int scale_mode, hipStream_t st) {
+static int launch_attn_v1_t(const AttnParams& p, int scale_mode, hipStream_t st) {
     const int grid = p.B * p.Hq * p.nqb;
     const size_t lds = (size_t)kStages * 2 * 64 * D;
     if (scale_mode == QATTN_SCALE_TOKEN) {
-        auto kern = attn_fwd_kernel<D, FMT, FMT, CAUSAL, true>;
+        auto kern = attn_fwd_kernel_v1<D, FMT, FMT, CAUSAL, true>;
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
     } else {
-        auto kern = attn_fwd_kernel<D, FMT, FMT, CAUSAL, false>;
+        auto kern = attn_fwd_kernel_v1<D, FMT, FMT, CAUSAL, false>;
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
     }
@@ -343,65 +300,18 @@ static int launch_attn(const AttnParams& p, int scale_mode, hipStream_t st) {
 }
 
 template <int D>
-static int launch_attn_d(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (fmt == QATTN_FMT_E4M3) return causal ? launch_attn<D, QATTN_FMT_E4M3, true>(p, scale_mode, st) : launch_attn<D, QATTN_FMT_E4M3, false>(p, scale_mode, st);
-    return causal ? launch_attn<D, QATTN_FMT_E5M2, true>(p, scale_mode, st) : launch_attn<D, QATTN_FMT_E5M2, false>(p, scale_mode, st);
+static int launch_attn_v1_d(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) {
+    if (fmt == QATTN_FMT_E4M3) return causal ? launch_attn_v1_t<D, QATTN_FMT_E4M3, true>(p, scale_mode, st) : launch_attn_v1_t<D, QATTN_FMT_E4M3, false>(p, scale_mode, st);
+    return causal ? launch_attn_v1_t<D, QATTN_FMT_E5M2, true>(p, scale_mode, st) : launch_attn_v1_t<D, QATTN_FMT_E5M2, false>(p, scale_mode, st);
+}
+
+
+
+
+int launch_attn_v1(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
+    if (D == 64) return launch_attn_v1_d<64>(p, fmt, causal, scale_mode, st);
+    if (D == 128) return launch_attn_v1_d<128>(p, fmt, causal, scale_mode, st);
+    return launch_attn_v1_d<256>(p, fmt, causal, scale_mode, st);
 }
 
 }  // namespace qattn
-
-using namespace qattn;
-
-extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, void* out, float* lse,
-                                           const float* scale_q, const float* scale_k, const float* scale_v, int B,
-                                           int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt,
-                                           int scale_mode, int is_causal, float sm_scale, void* stream) {
-    if (!q8 || !k8 || !v8 || !out || !scale_q || !scale_k) return QATTN_ERR_INVALID_ARG;
-    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
-    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;  // nn.py:45-49
-    if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;                    // tk/attention.py:398-399
-    if (qk_fmt != QATTN_FMT_E4M3 && qk_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (v_fmt != qk_fmt) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (out_fmt != QATTN_FMT_BF16 && out_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
-    AttnParams p;
-    p.q = (const unsigned char*)q8; p.k = (const unsigned char*)k8; p.v = (const unsigned char*)v8;
-    p.out = out; p.lse = lse; p.sq = scale_q; p.sk = scale_k; p.sv = scale_v;
-    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
-    p.nqb = ceil_div(Sq, kQPerWG);
-    p.nchunks = ceil_div(Skv, 64);
-    p.out_fmt = out_fmt;
-    p.xcd_remap = ((B * Hq) % 8 == 0) ? 1 : 0;
-    const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
-    p.sm_log2e = sm * 1.4426950408889634f;
-    hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (D == 64) rc = launch_attn_d<64>(p, qk_fmt, is_causal, scale_mode, st);
-    else if (D == 128) rc = launch_attn_d<128>(p, qk_fmt, is_causal, scale_mode, st);
-    else rc = launch_attn_d<256>(p, qk_fmt, is_causal, scale_mode, st);
-    if (rc != QATTN_OK) return rc;
-    return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
-}
-
-extern "C" int qattn_abi_version(void) { return QATTN_ABI_VERSION; }
-
-extern "C" const char* qattn_strerror(int code) {
-    switch (code) {
-        case QATTN_OK: return "ok";
-        case QATTN_ERR_INVALID_ARG: return "invalid argument (null pointer, non-positive dimension or unknown enum)";
-        case QATTN_ERR_UNSUPPORTED_DIM: return "unsupported head dimension (need 64, 128 or 256) or Hq not divisible by Hkv";
-        case QATTN_ERR_UNSUPPORTED_FMT: return "unsupported element format / layout combination";
-        case QATTN_ERR_WORKSPACE: return "workspace missing or too small";
-        case QATTN_ERR_LAUNCH: return "HIP kernel launch failed";
-        case QATTN_ERR_DEVICE: return "current HIP device is not gfx950 (MI355X)";
-        default: return "unknown qattn error code";
-    }
-}
-
-extern "C" int qattn_check_device(void) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return QATTN_ERR_DEVICE;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return QATTN_ERR_DEVICE;
-    return __builtin_strstr(prop.gcnArchName, "gfx950") ? QATTN_OK : QATTN_ERR_DEVICE;
-}
