@@ -1,12 +1,30 @@
 // qattn_api.hip -- C-ABI entry points of libqattn_hip.so that are not in qattn_quant.hip (include/qattn.h).
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 #include "qattn_attn.h"
 
 using namespace qattn;
 
 // Development switch: QATTN_KERNEL_VARIANT=1 selects the first (non-pipelined) kernel structure for A/B runs.
+// QATTN_EXACT_EXP=1 disables the byte-exponential fast path (see qattn_attn_v2.hip).
+static int exact_exp() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("QATTN_EXACT_EXP");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 static int kernel_variant() {
     static int v = -1;
     if (v < 0) {
@@ -33,17 +51,46 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     p.q = (const unsigned char*)q8; p.k = (const unsigned char*)k8; p.v = (const unsigned char*)v8;
     p.out = out; p.lse = lse; p.sq = scale_q; p.sk = scale_k; p.sv = scale_v;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
-    p.nqb = ceil_div(Sq, kQPerWG);
+    const bool use_v1 = (D != 128 || kernel_variant() == 1);
+    p.waves = use_v1 ? kWaves : env_int("QATTN_V2_WAVES", 8);
+    p.lds_pad = env_int("QATTN_V2_LDS", 0);
+    p.dbg = env_int("QATTN_V2_DBG", 0);
+    p.dbg_buf = nullptr;
+    static unsigned long long* dbg_dev = nullptr;
+    const long n_dbg_waves = (long)B * Hq * ceil_div(Sq, p.waves * kQPerWave) * p.waves;
+    if (p.dbg & 16) {
+        if (!dbg_dev) (void)hipMalloc(&dbg_dev, sizeof(unsigned long long) * 2 * (1 << 20));
+        p.dbg_buf = dbg_dev;
+        (void)hipMemsetAsync(dbg_dev, 0, sizeof(unsigned long long) * 2 * n_dbg_waves, (hipStream_t)stream);
+    }
+    p.nqb = ceil_div(Sq, p.waves * kQPerWave);
     p.nchunks = ceil_div(Skv, 64);
     p.out_fmt = out_fmt;
     p.xcd_remap = ((B * Hq) % 8 == 0) ? 1 : 0;
     const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
     p.sm_log2e = sm * 1.4426950408889634f;
+    p.exact_exp = exact_exp();
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (D != 128 || kernel_variant() == 1) rc = launch_attn_v1(p, D, qk_fmt, is_causal, scale_mode, st);
+    if (use_v1) rc = launch_attn_v1(p, D, qk_fmt, is_causal, scale_mode, st);
     else rc = launch_attn_v2(p, D, qk_fmt, is_causal, scale_mode, st);
     if (rc != QATTN_OK) return rc;
+    if ((p.dbg & 16) && p.dbg_buf) {  // diagnostic build path only: synchronises and prints per-wave sweep statistics
+        static int printed = 0;
+        (void)hipStreamSynchronize(st);
+        if (printed++ == 3) {
+            std::vector<unsigned long long> h(2 * n_dbg_waves);
+            (void)hipMemcpy(h.data(), p.dbg_buf, sizeof(unsigned long long) * 2 * n_dbg_waves, hipMemcpyDeviceToHost);
+            std::vector<double> cyc, clk;
+            for (long i = 0; i < n_dbg_waves; i++) if (h[2 * i + 1]) { cyc.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
+            if (!cyc.empty()) {
+                std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+                const int iters = ceil_div(Skv, 64) + 2;
+                fprintf(stderr, "[qattn dbg] waves=%zu sweep cycles median=%.0f (%.1f per iteration over %d) p10=%.0f p90=%.0f | in-kernel clock median %.3f GHz\n",
+                        cyc.size(), cyc[cyc.size() / 2], cyc[cyc.size() / 2] / iters, iters, cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10], clk[clk.size() / 2]);
+            }
+        }
+    }
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
 

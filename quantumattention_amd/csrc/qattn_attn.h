@@ -10,6 +10,9 @@ constexpr int kQPerWave = 32;                // query rows per wave (MFMA N)
 constexpr int kQPerWG = kWaves * kQPerWave;  // 256
 constexpr float kPShift = 5.0f;              // P' = P * 2^5 keeps small probabilities above the e4m3 subnormals
 constexpr float kRescaleThr = 3.0f;          // log2 units: P' <= 2^(5+3) = 256 < 448 (e4m3 max)
+constexpr float kPShiftByte = 7.0f;          // byte-exponential mode: P' = P * 2^7 (keeps bytes out of the e4m3 subnormals,
+constexpr float kRescaleThrByte = 1.0f;      //   where byte ~ 8x+56 is not an exponential), P' <= 2^8 -> byte <= 120 < 0x7e
+constexpr float kByteBias = -0.3f;           // centres the (1+m/8 >= 2^(m/8)) mantissa error of the byte exponential
 constexpr int kTwoTermKeys = 1024;           // rows that see fewer keys than this use hi+lo (two-term) fp8 P
 
 struct AttnParams {
@@ -27,6 +30,11 @@ struct AttnParams {
     int out_fmt;
     int xcd_remap;   // 1: each XCD gets a contiguous range of heads
     float sm_log2e;  // sm_scale * log2(e)
+    int exact_exp;   // 1: v_exp_f32 + RNE fp8 conversion everywhere (no byte-exponential fast path)
+    int waves;       // waves per workgroup of the v2 kernel (8 or 4): nqb is computed for waves*32 rows
+    int lds_pad;     // development: force this dynamic-LDS size (occupancy experiments), 0 = natural
+    unsigned long long* dbg_buf;  // development: per-wave {cycles, realtime ticks} of the KV sweep when dbg & 16
+    int dbg;         // development: 16 = stamp per-wave sweep cycles into dbg_buf
 };
 
 template <int CBSZ, int BLGP>

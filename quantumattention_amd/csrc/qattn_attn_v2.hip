@@ -30,31 +30,44 @@ namespace qattn {
 
 constexpr int kStagesV2 = 3;
 
-template <int D>
-__device__ __forceinline__ void stage_kv(const unsigned char* ksrc, const unsigned char* vsrc, unsigned char* lds_stage,
-                                         int wave, int lane) {
-    // [K chunk | V chunk] = 2*64*D bytes, linear; every wave-instruction moves 1 KiB (64 lanes x 16 B)
+// K/V staging through registers (issue early / write late): LDS-DMA pieces measured ~300 issue cycles each inside
+// this loop (profiles/r01_ablation.md), plain global_load_dwordx4 + ds_write_b128 a few tens.
+// One stage image = [K chunk | V chunk] = 2*64*D bytes, linear; thread (wave, lane) owns 16-byte pieces
+// r*(NW*1024) + wave*1024 + lane*16, r < ROUNDS.
+template <int D, int NW>
+struct StageRegs {
+    static constexpr int ROUNDS = 2 * 64 * D / (NW * 64 * 16);
+    v4i r[ROUNDS];
+};
+template <int D, int NW>
+__device__ __forceinline__ void stage_load(StageRegs<D, NW>& sr, const unsigned char* ksrc, const unsigned char* vsrc,
+                                           int wave, int lane) {
     constexpr int CH = 64 * D;
-    constexpr int ROUNDS = 2 * CH / (kThreads * 16);
-    const int wave_base = wave << 10;  // wave-uniform
 #pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const int o = r * (kThreads * 16) + wave_base;
+    for (int r = 0; r < StageRegs<D, NW>::ROUNDS; r++) {
+        const int o = r * (NW * 1024) + (wave << 10);
         const unsigned char* src = (o < CH ? ksrc + o : vsrc + (o - CH)) + (lane << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_stage + o), 16, 0, 0);
+        sr.r[r] = *reinterpret_cast<const v4i*>(src);
     }
 }
+template <int D, int NW>
+__device__ __forceinline__ void stage_write(const StageRegs<D, NW>& sr, unsigned char* lds_stage, int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < StageRegs<D, NW>::ROUNDS; r++)
+        *reinterpret_cast<v4i*>(lds_stage + r * (NW * 1024) + (wave << 10) + (lane << 4)) = sr.r[r];
+}
 
-template <int D, bool TWO>
+template <int D, bool TWO, bool BYTE>
 struct WaveState {
     static constexpr int MB = D / 32;
     v16f o[MB];             // O^T accumulators
     v16f s[2][2];           // S^T ping-pong: s[t&1] holds chunk t's two 32-key tiles
     v8i p[2];               // P^T (e4m3) ping-pong: p[t&1] holds chunk t
     v8i pl[TWO ? 2 : 1];    // low term of the two-term split (unused when !TWO)
+    v8i vpre[2];            // V fragments (row blocks 0,1) of the NEXT iteration's PV, read one iteration ahead
     float m_run;   // running max of the raw scores
-    float l_run;   // this lane's partial row sum of P'
+    float l_run;   // this lane's partial row sum of P' (exact-exp mode)
+    v16f l16;      // BYTE mode: every register = the full row sum of the quantised P', accumulated by a ones-row MFMA
     float c;       // scale_q*scale_k*sm_scale*log2(e)
 };
 
@@ -140,20 +153,42 @@ __device__ __forceinline__ void exp_group(const v16f& sx, int j, float c, float 
     pv[w] = ph;
 }
 
-#define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+// BYTE mode: 4 scores -> the e4m3 BYTES of 2^x directly.  For a normal e4m3 number byte = 8*(e+7) + m with value
+// 2^e*(1+m/8), so byte ~= 8*x + 56 (Schraudolph's exponent trick at 3 mantissa bits): one fma + one saturating
+// round-to-nearest v_cvt_pk_u8_f32 per score (profiles/r01_cvt_u8_probe.log) instead of fma + v_exp_f32 + half a
+// v_cvt_pk_fp8_f32 (~17 issue cycles -> ~6).  c8 = 8c, off8 = 8*(shift - m*c) + 56 + kByteBias.  -inf -> 0.
+__device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, float off8, v8i& pv, int w, int seed) {
+    unsigned b = (unsigned)seed;
+#pragma unroll
+    for (int i = 0; i < 4; i++) b = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(sx[4 * j + i], c8, off8), i, b);
+    asm volatile("" : "+v"(b));  // stays in this slot
+    pv[w] = (int)b;
+}
 
-// One pipelined iteration (1 <= t <= n_w): QK(t), softmax(t-1), PV(t-2), hand-placed in 8 MFMA slots.  PAR = t & 1.
-// Slot i = { MFMA i ; ds_reads of the fragment(s) slot i+1 needs ; softmax group i (4 scores) } -- the MFMA is first
-// in program order so the loads and the VALU slice issue underneath it.  QK^T goes first and PV last: S(t) is then
-// complete long before the next iteration's VALU reads it, and only the rare fix-up waits for the PV accumulators.
-// The Q^T fragments are parked in LDS (each lane re-reads its own 64 bytes per iteration): registers, not LDS
-// bandwidth, are the scarce resource at two waves per SIMD.
-template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO>
-__device__ __forceinline__ void full_step(WaveState<D, TWO>& st, const unsigned char* kbuf, const unsigned char* qbuf) {
+#define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define QATTN_SM_GROUP(FIRST, SX, J, MC, W, SEED)                                   \
+    do {                                                                            \
+        if (ABL & 4) break;                                                         \
+        if (BYTE) byte_group(SX, J, cx, MC, pc, W, SEED);                            \
+        else exp_group<TWO, FIRST>(SX, J, cx, MC, acc, pc, pcl, W, SEED);            \
+    } while (0)
+
+// One pipelined iteration (1 <= t <= n_w): PV(t-2), [row-sum MFMA], QK(t), softmax(t-1) in hand-placed MFMA slots.
+// PAR = t & 1.  A lone wave measured ~1800 cycles per iteration when every MFMA waited for LDS fragments issued one
+// short slot earlier, so the operand pipeline is two slots deep: slot i issues the ds_reads slot i+2 consumes, PV goes
+// first on V fragments that were read during the PREVIOUS iteration (stage(t-1) has been visible since that barrier),
+// and QK^T goes last on K fragments requested at the top of the iteration.  The softmax slices (4 scores each) sit
+// under the MFMAs; only the rare fix-up waits for accumulators.  Q^T fragments are parked in LDS (registers, not LDS
+// bandwidth, are the scarce resource at two waves per SIMD).
+//   kbuf  : stage(t),   K part  (+ lane offset)      vprev : stage(t-1), V part = V(t-2)
+//   vnext : stage(t),   V part = V(t-1) (prefetch for the next iteration)
+template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0>
+__device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const unsigned char* kbuf, const unsigned char* vprev,
+                                          const unsigned char* vnext, const unsigned char* qbuf) {
     static_assert(D == 128, "hand-placed slots are written for D = 128");
-    constexpr int CH = 64 * D;
+    // ABL (timing-only ablations, results wrong): 4 = no softmax VALU, 8 = no LDS fragment reads (operands = a fixed register set)
+    auto LDSF = [&](const unsigned char* ptr) -> v8i { if (ABL & 8) return st.vpre[0]; return lds_read_frag(ptr); };
     constexpr int PL_R = TWO ? PAR : 0, PL_W = TWO ? (PAR ^ 1) : 0;
-    const unsigned char* vbuf = kbuf + CH;
     v16f& sn0 = st.s[PAR][0];            // S(t)   tile 0 (keys  0..31 of chunk t)
     v16f& sn1 = st.s[PAR][1];            //        tile 1 (keys 32..63)
     const v16f& sc0 = st.s[PAR ^ 1][0];  // S(t-1) tiles: the chunk being exponentiated
@@ -162,74 +197,84 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO>& st, const unsigned 
     v8i& pcl = st.pl[PL_W];
     const v8i& pp = st.p[PAR];           // P(t-2) consumed by PV
     const v8i& ppl = st.pl[PL_R];
-    const float c = st.c, mc = kPShift - st.m_run * st.c;
+    constexpr float SHIFT = BYTE ? kPShiftByte : kPShift, THR = BYTE ? kRescaleThrByte : kRescaleThr;
+    const float c = st.c;
+    // exact mode: p' = exp2(s*c + mc);  byte mode: byte = rne(s*c8 + mc)  (c8 = 8c, mc = 8*(shift - m*c) + 56 + bias)
+    const float cx = BYTE ? 8.0f * c : c;
+    const float mc = BYTE ? __builtin_fmaf(-8.0f * st.m_run, c, 8.0f * SHIFT + 56.0f + kByteBias) : SHIFT - st.m_run * c;
     float acc[4];
 
-    // pre: first operands in flight, chunk max of S(t-1) underneath their latency
-    v8i qf = lds_read_frag(qbuf);              // Q^T k-step 0
-    v8i fa = lds_read_frag(kbuf + (0 << 11));  // K (tile 0, k-step 0)
+    // slot 0: O0 += V0.P(t-2)            reads: V2            VALU: max over tile 0
+    st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], pp, st.o[0]);
+    if (TWO) st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], ppl, st.o[0]);
+    v8i fc = LDSF(vprev + (2 << 11));
     float mx = fmaxf(fmaxf(sc0[0], sc0[1]), sc0[2]);
 #pragma unroll
     for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc0[r]), sc0[r + 1]);
-    mx = fmaxf(fmaxf(mx, sc0[15]), sc1[0]);
-#pragma unroll
-    for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc1[r]), sc1[r + 1]);
-    mx = fmaxf(mx, sc1[15]);
+    mx = fmaxf(mx, sc0[15]);
     QATTN_SLOT_FENCE();
-    // slot 0: S0 = K(0,0).Q0
+    // slot 1: O1 += V1.P(t-2)            reads: V3            VALU: max over tile 1, group 0
+    st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], pp, st.o[1]);
+    if (TWO) st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], ppl, st.o[1]);
+    v8i fd = LDSF(vprev + (3 << 11));
+    mx = fmaxf(fmaxf(mx, sc1[0]), sc1[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sc1[r]), sc1[r + 1]);
+    QATTN_SM_GROUP(true, sc0, 0, mc, 0, pp[0]);
+    QATTN_SLOT_FENCE();
+    // slot 2: O2 += V2.P(t-2)            reads: Q k-step 0, K(tile 0, k-step 0)      VALU: group 1
+    st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, pp, st.o[2]);
+    if (TWO) st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
+    v8i qf = LDSF(qbuf);
+    v8i ka = LDSF(kbuf + (0 << 11));
+    QATTN_SM_GROUP(false, sc0, 1, mc, 1, pc[0]);
+    QATTN_SLOT_FENCE();
+    // slot 3: O3 += V3.P(t-2)            reads: K(tile 1, k-step 0)                  VALU: group 2
+    st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, pp, st.o[3]);
+    if (TWO) st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
+    v8i kb = LDSF(kbuf + (2 << 11));
+    QATTN_SM_GROUP(false, sc0, 2, mc, 2, pc[1]);
+    QATTN_SLOT_FENCE();
+    // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
+    if (BYTE) {
+        v8i ones;
+#pragma unroll
+        for (int w = 0; w < 8; w++) ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;  // 1.0 in e4m3 / e5m2
+        st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(ones, pp, st.l16);
+    }
+    v8i qg = LDSF(qbuf + (1 << 11));   // Q k-step 1
+    v8i kc = LDSF(kbuf + (1 << 11));   // K(tile 0, k-step 1)
+    QATTN_SM_GROUP(false, sc0, 3, mc, 3, pc[2]);
+    QATTN_SLOT_FENCE();
+    // slot 5: S0 = K(0,0).Q0             reads: K(tile 1, k-step 1)                  VALU: group 4
 #pragma unroll
     for (int r = 0; r < 16; r++) { sn0[r] = 0.0f; sn1[r] = 0.0f; }
-    sn0 = mfma_f8<QK_FMT, QK_FMT>(fa, qf, sn0);
-    v8i fb = lds_read_frag(kbuf + (2 << 11));  // K (tile 1, k-step 0)
-    exp_group<TWO, true>(sc0, 0, c, mc, acc, pc, pcl, 0, pp[0]);
+    sn0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf, sn0);
+    v8i kd = LDSF(kbuf + (3 << 11));
+    QATTN_SM_GROUP(false, sc1, 0, mc, 4, pc[3]);
     QATTN_SLOT_FENCE();
-    // slot 1: S1 = K(1,0).Q0
-    sn1 = mfma_f8<QK_FMT, QK_FMT>(fb, qf, sn1);
-    qf = lds_read_frag(qbuf + (1 << 11));      // Q^T k-step 1
-    fa = lds_read_frag(kbuf + (1 << 11));      // K (tile 0, k-step 1)
-    exp_group<TWO, false>(sc0, 1, c, mc, acc, pc, pcl, 1, pc[0]);
+    // slot 6: S1 = K(1,0).Q0             reads: next iteration's V0                  VALU: group 5
+    sn1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf, sn1);
+    st.vpre[0] = LDSF(vnext + (0 << 11));
+    QATTN_SM_GROUP(false, sc1, 1, mc, 5, pc[4]);
     QATTN_SLOT_FENCE();
-    // slot 2: S0 += K(0,1).Q1
-    sn0 = mfma_f8<QK_FMT, QK_FMT>(fa, qf, sn0);
-    fb = lds_read_frag(kbuf + (3 << 11));      // K (tile 1, k-step 1)
-    exp_group<TWO, false>(sc0, 2, c, mc, acc, pc, pcl, 2, pc[1]);
+    // slot 7: S0 += K(0,1).Q1            reads: next iteration's V1                  VALU: group 6
+    sn0 = mfma_f8<QK_FMT, QK_FMT>(kc, qg, sn0);
+    st.vpre[1] = LDSF(vnext + (1 << 11));
+    QATTN_SM_GROUP(false, sc1, 2, mc, 6, pc[5]);
     QATTN_SLOT_FENCE();
-    // slot 3: S1 += K(1,1).Q1
-    sn1 = mfma_f8<QK_FMT, QK_FMT>(fb, qf, sn1);
-    fa = lds_read_frag(vbuf + (0 << 11));      // V block 0
-    exp_group<TWO, false>(sc0, 3, c, mc, acc, pc, pcl, 3, pc[2]);
-    QATTN_SLOT_FENCE();
-    // slot 4: O0 += V0.P(t-2)
-    st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fa, pp, st.o[0]);
-    if (TWO) st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fa, ppl, st.o[0]);
-    fb = lds_read_frag(vbuf + (1 << 11));
-    exp_group<TWO, false>(sc1, 0, c, mc, acc, pc, pcl, 4, pc[3]);
-    QATTN_SLOT_FENCE();
-    // slot 5
-    st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fb, pp, st.o[1]);
-    if (TWO) st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fb, ppl, st.o[1]);
-    fa = lds_read_frag(vbuf + (2 << 11));
-    exp_group<TWO, false>(sc1, 1, c, mc, acc, pc, pcl, 5, pc[4]);
-    QATTN_SLOT_FENCE();
-    // slot 6
-    st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fa, pp, st.o[2]);
-    if (TWO) st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fa, ppl, st.o[2]);
-    fb = lds_read_frag(vbuf + (3 << 11));
-    exp_group<TWO, false>(sc1, 2, c, mc, acc, pc, pcl, 6, pc[5]);
-    QATTN_SLOT_FENCE();
-    // slot 7
-    st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fb, pp, st.o[3]);
-    if (TWO) st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fb, ppl, st.o[3]);
-    exp_group<TWO, false>(sc1, 3, c, mc, acc, pc, pcl, 7, pc[6]);
+    // slot 8: S1 += K(1,1).Q1                                                        VALU: group 7, max exchange
+    sn1 = mfma_f8<QK_FMT, QK_FMT>(kd, qg, sn1);
+    QATTN_SM_GROUP(false, sc1, 3, mc, 7, pc[6]);
     {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    float ls = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     QATTN_SLOT_FENCE();
     // rare fix-up: some row's max grew by more than the threshold (always on the first chunk: m_run = -1e30):
-    // rescale everything accumulated so far (O includes PV(t-2)) and redo this chunk's exponentials
-    if (__builtin_expect(__any((mx - st.m_run) * c > kRescaleThr) != 0, 0)) {
+    // rescale everything accumulated so far (O and the row sum include chunk t-2) and redo this chunk's exponentials
+    if (__builtin_expect(__any((mx - st.m_run) * c > THR) != 0, 0)) {
         const float m_new = fmaxf(st.m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((st.m_run - m_new) * c);
 #pragma unroll
@@ -237,25 +282,28 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO>& st, const unsigned 
 #pragma unroll
             for (int r = 0; r < 16; r++) st.o[m][r] *= alpha;
         st.l_run *= alpha;
+        if (BYTE) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) st.l16[r] *= alpha;
+        }
         st.m_run = m_new;
-        const float mc2 = kPShift - m_new * c;
-        exp_group<TWO, true>(sc0, 0, c, mc2, acc, pc, pcl, 0, 0);
+        const float mc2 = BYTE ? __builtin_fmaf(-8.0f * m_new, c, 8.0f * SHIFT + 56.0f + kByteBias) : SHIFT - m_new * c;
+        QATTN_SM_GROUP(true, sc0, 0, mc2, 0, 0);
 #pragma unroll
-        for (int j = 1; j < 4; j++) exp_group<TWO, false>(sc0, j, c, mc2, acc, pc, pcl, j, 0);
+        for (int j = 1; j < 4; j++) QATTN_SM_GROUP(false, sc0, j, mc2, j, 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) exp_group<TWO, false>(sc1, j, c, mc2, acc, pc, pcl, 4 + j, 0);
-        ls = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        for (int j = 0; j < 4; j++) QATTN_SM_GROUP(false, sc1, j, mc2, 4 + j, 0);
+        ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
     st.l_run += ls;
 }
 
 // The KV sweep of one wave.  Returns with st.o / st.l_run / st.m_run final.
-template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO>
-__device__ __forceinline__ void kv_sweep(WaveState<D, TWO>& st, const AttnParams& p, unsigned char* smem,
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0>
+__device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt) {
     constexpr int CH = 64 * D, STAGE = 2 * CH;
-    constexpr int ROUNDS = 2 * CH / (kThreads * 16);
     const int hh = lane >> 5;
     const int T = n_wg + 2;  // iterations t = 0 .. n_wg+1 : QK(t), softmax(t-1), PV(t-2)
     const int frag_lane_off = (hh << 10) + ((lane & 31) << 4);
@@ -265,25 +313,35 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO>& st, const AttnParams
         st.pl[0][w] = 0;
         if (TWO) st.pl[TWO ? 1 : 0][w] = 0;
     }
-    auto stage_for = [&](int t) {
-        const int kc = min(t, p.nchunks - 1), vc = min(max(t - 2, 0), p.nchunks - 1);
-        stage_kv<D>(kg + (long)kc * CH, vg + (long)vc * CH, smem + (t % kStagesV2) * STAGE, wave, lane);
+    // Ring protocol (3 stages, stage(t) = {K(t), V(t-1)} lives in slot t%3):
+    //   iteration t:  barrier(t)  ->  ds_write the registers holding stage(t+1) (loaded during iteration t-1) into
+    //   slot (t+1)%3 (its old content, stage(t-2), was last read in iteration t-1)  ->  issue the global loads of
+    //   stage(t+2)  ->  compute on stage(t) [K] and stage(t-1) [V].  barrier(t+1) publishes stage(t+1).
+    StageRegs<D, NW> sr;
+    auto load_for = [&](int t) {
+        const int kc = min(t, p.nchunks - 1), vc = min(max(t - 1, 0), p.nchunks - 1);  // stage(t) = {K(t), V(t-1)}
+        stage_load<D, NW>(sr, kg + (long)kc * CH, vg + (long)vc * CH, wave, lane);
     };
-    // every iteration t (all T of them, on every wave) starts with: stage(t) landed -> barrier -> refill stage(t+2)
+    // prologue: stage(0) straight into LDS, stage(1) left in flight in the registers
+    load_for(0);
+    stage_write<D, NW>(sr, smem, wave, lane);
+    load_for(1);
+    // every iteration t (all T of them, on every wave) starts here
     auto sync_iter = [&](int t) -> const unsigned char* {
-        // stage(t)'s DMA was issued two iterations ago; at most stage(t+1)'s may stay in flight
-        if (t + 1 < T) { if (ROUNDS == 1) wait_vmcnt<1>(); else if (ROUNDS == 2) wait_vmcnt<2>(); else wait_vmcnt<4>(); }
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        // every wave is past its reads of stage (t-1)%3 == (t+2)%3: refill it
-        if (t + 2 < T) stage_for(t + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of stage(t) are in LDS
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        if (!(ABL & 1)) {
+            if (t + 1 < T) stage_write<D, NW>(sr, smem + ((t + 1) % kStagesV2) * STAGE, wave, lane);  // waits vmcnt for sr
+            if (t + 2 < T) load_for(t + 2);
+        }
         return smem + (t % kStagesV2) * STAGE + frag_lane_off;
     };
     auto full = [&](auto par_tag, int t) {
         constexpr int PAR = decltype(par_tag)::value;
         const unsigned char* kbuf = sync_iter(t);
+        const unsigned char* vprev = smem + ((t - 1) % kStagesV2) * STAGE + CH + frag_lane_off;
         prep_scores<CAUSAL, TOKEN>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
-        full_step<D, QK_FMT, V_FMT, PAR, TWO>(st, kbuf, qbuf);
+        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL>(st, kbuf, vprev, kbuf + CH, qbuf);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -292,6 +350,8 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO>& st, const AttnParams
     {
         const unsigned char* kbuf = sync_iter(0);
         qk_chunk<QK_FMT, D>(kbuf, qbuf, st.s[0][0], st.s[0][1]);
+        st.vpre[0] = lds_read_frag(kbuf + CH + (0 << 11));  // stage(0)'s V part (= V(0), multiplied by P = 0 at t = 1)
+        st.vpre[1] = lds_read_frag(kbuf + CH + (1 << 11));
     }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
@@ -303,11 +363,29 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO>& st, const AttnParams
         full(P1{}, t);
         ++t;
     }
-    // t = n_w + 1: the last chunk's PV
+    // t = n_w + 1: the last chunk's PV (V(t-2) lives in stage(t-1); its row blocks 0,1 are already in vpre)
     {
-        const unsigned char* kbuf = sync_iter(t);
-        if (t & 1) pv_chunk<V_FMT, D, TWO>(kbuf + CH, st.p[1], st.pl[TWO ? 1 : 0], st.o);
-        else pv_chunk<V_FMT, D, TWO>(kbuf + CH, st.p[0], st.pl[0], st.o);
+        (void)sync_iter(t);
+        const unsigned char* vprev = smem + ((t - 1) % kStagesV2) * STAGE + CH + frag_lane_off;
+        const v8i fc = lds_read_frag(vprev + (2 << 11)), fd = lds_read_frag(vprev + (3 << 11));
+        const v8i& pp = (t & 1) ? st.p[1] : st.p[0];
+        const v8i& ppl = (TWO && (t & 1)) ? st.pl[TWO ? 1 : 0] : st.pl[0];
+        st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], pp, st.o[0]);
+        st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], pp, st.o[1]);
+        st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, pp, st.o[2]);
+        st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, pp, st.o[3]);
+        if (TWO) {
+            st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], ppl, st.o[0]);
+            st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], ppl, st.o[1]);
+            st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
+            st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
+        }
+        if (BYTE) {
+            v8i ones;
+#pragma unroll
+            for (int w = 0; w < 8; w++) ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;
+            st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(ones, pp, st.l16);
+        }
         ++t;
     }
     // causal: waves whose rows end earlier keep the workgroup's barrier / DMA cadence until the last wave is done
@@ -315,8 +393,8 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO>& st, const AttnParams
 }
 
 // QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
-template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO>
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v2(const AttnParams p, const int qb_lo, const int qb_n) {
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p, const int qb_lo, const int qb_n) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
     constexpr int KS = D / 64;      // QK^T k-steps
@@ -335,7 +413,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v2(const AttnPara
     const int b = head / p.Hq, h = head % p.Hq;
     const int hkv = h / (p.Hq / p.Hkv);
     const long kv_head = (long)b * p.Hkv + hkv;
-    const int q0_wg = qb * kQPerWG;
+    constexpr int QWG = NW * kQPerWave;
+    const int q0_wg = qb * QWG;
     const int q0 = q0_wg + wave * kQPerWave;  // first query row of this wave
     const int qrow = q0 + ql;                 // this lane's query row
 
@@ -343,12 +422,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v2(const AttnPara
     const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
 
     // chunks the workgroup / this wave must visit (causal: up to the diagonal of the last row)
-    const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + kQPerWG, p.Sq) - 1) / 64 + 1) : p.nchunks;
+    const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + QWG, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
 
-    // start the DMA ring: stage(t) = {K chunk t, V chunk t-2}
-    stage_kv<D>(kg, vg, smem, wave, lane);
-    stage_kv<D>(kg + (long)min(1, p.nchunks - 1) * CH, vg, smem + STAGE, wave, lane);
 
     // Q^T fragments: global -> this lane's own slots of the workgroup's Q area in LDS (behind the K/V ring);
     // only the writing lane ever reads them back, so no barrier is needed (the compiler orders the lane's own
@@ -372,7 +448,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v2(const AttnPara
     else c = p.sm_log2e * p.sq[(long)b * p.Hq + h] * p.sk[kv_head];
     const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
 
-    WaveState<D, TWO> st;
+    WaveState<D, TWO, BYTE> st;
+#pragma unroll
+    for (int r = 0; r < 16; r++) st.l16[r] = 0.0f;
 #pragma unroll
     for (int m = 0; m < MB; m++)
 #pragma unroll
@@ -380,13 +458,25 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v2(const AttnPara
     st.m_run = -1.0e30f;  // finite sentinel: the first chunk always takes the fix-up branch
     st.l_run = 0.0f;
     st.c = c;
-    kv_sweep<D, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt);
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt);
+    if (p.dbg & 16) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            const long wid = (long)blockIdx.x * NW + wave;
+            p.dbg_buf[2 * wid] = t1 - dbg_t0;
+            p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
+        }
+    }
     const float m_run = st.m_run, l_run = st.l_run;
     v16f (&o)[MB] = st.o;
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, convert, store
     float l_tot;
-    {
+    if (BYTE) {
+        l_tot = st.l16[0];  // the ones-row MFMA already summed over both half-waves' keys
+    } else {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
@@ -421,49 +511,73 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v2(const AttnPara
         }
         if (p.lse && hh == 0) {
             // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l')
-            p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = 0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot);
+            p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = 0.6931471805599453f * (m_run * c - (BYTE ? kPShiftByte : kPShift)) + __logf(l_tot);
         }
     }
 }
 
-template <int D, int FMT, bool CAUSAL, bool TOKEN, bool TWO>
+template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE>
 static int launch_attn_v2_one(const AttnParams& p, int qb_lo, int qb_n, hipStream_t st) {
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
-    const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)kQPerWG * D;  // K/V ring + parked Q^T fragments
-    auto kern = attn_fwd_kernel_v2<D, FMT, FMT, CAUSAL, TOKEN, TWO>;
+    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D;  // K/V ring + parked Q^T fragments
+    if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
+    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, TWO, BYTE>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p, qb_lo, qb_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n);
     return QATTN_OK;
 }
 
 // Query blocks whose first row sees fewer than kTwoTermKeys keys run the two-term (hi+lo fp8 P) instantiation,
 // the rest the one-term one: two launches over disjoint q-block ranges of the same output tensor.
-template <int D, int FMT, bool CAUSAL>
+template <int D, int NW, int FMT, bool CAUSAL>
 static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st) {
     int n_two;  // leading q-blocks that need two-term P
-    if (CAUSAL) n_two = min(p.nqb, ceil_div(min(kTwoTermKeys, p.Skv), kQPerWG));
+    if (CAUSAL) n_two = min(p.nqb, ceil_div(min(kTwoTermKeys, p.Skv), NW * kQPerWave));
     else n_two = p.Skv < kTwoTermKeys ? p.nqb : 0;
+    if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
+        // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
+        const int grid = p.B * p.Hq * p.nqb;
+        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D;
+#define QATTN_ABL_CASE(M)                                                                                          \
+        case M: {                                                                                                  \
+            auto kern = attn_fwd_kernel_v2<D, 8, QATTN_FMT_E4M3, QATTN_FMT_E4M3, false, false, false, true, M>;    \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, 0, p.nqb);                             \
+            return QATTN_OK;                                                                                       \
+        }
+        switch ((p.dbg >> 8) == 0 ? 0 : (p.dbg & 15)) {
+            QATTN_ABL_CASE(1) QATTN_ABL_CASE(2) QATTN_ABL_CASE(4) QATTN_ABL_CASE(8) QATTN_ABL_CASE(12) QATTN_ABL_CASE(15) QATTN_ABL_CASE(3) QATTN_ABL_CASE(11)
+            default: break;
+        }
+#undef QATTN_ABL_CASE
+    }
+    // byte-exponential fast path for the one-term launch, unless the caller wants the LSE (needs the exact row sum)
+    // or exact exponentials were requested (QATTN_EXACT_EXP=1)
+    const bool byte_exp = !p.exact_exp && p.lse == nullptr;
     int rc;
     if (scale_mode == QATTN_SCALE_TOKEN) {
-        rc = launch_attn_v2_one<D, FMT, CAUSAL, true, false>(p, n_two, p.nqb - n_two, st);
-        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, FMT, CAUSAL, true, true>(p, 0, n_two, st);
+        if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, true>(p, n_two, p.nqb - n_two, st);
+        else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, false>(p, n_two, p.nqb - n_two, st);
+        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, true, false>(p, 0, n_two, st);
     } else {
-        rc = launch_attn_v2_one<D, FMT, CAUSAL, false, false>(p, n_two, p.nqb - n_two, st);
-        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, FMT, CAUSAL, false, true>(p, 0, n_two, st);
+        if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, true>(p, n_two, p.nqb - n_two, st);
+        else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, false>(p, n_two, p.nqb - n_two, st);
+        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true, false>(p, 0, n_two, st);
     }
     return rc;
 }
 
-template <int D>
+template <int D, int NW>
 static int launch_attn_v2_d(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (fmt == QATTN_FMT_E4M3) return causal ? launch_attn_v2_t<D, QATTN_FMT_E4M3, true>(p, scale_mode, st) : launch_attn_v2_t<D, QATTN_FMT_E4M3, false>(p, scale_mode, st);
-    return causal ? launch_attn_v2_t<D, QATTN_FMT_E5M2, true>(p, scale_mode, st) : launch_attn_v2_t<D, QATTN_FMT_E5M2, false>(p, scale_mode, st);
+    if (fmt == QATTN_FMT_E4M3) return causal ? launch_attn_v2_t<D, NW, QATTN_FMT_E4M3, true>(p, scale_mode, st) : launch_attn_v2_t<D, NW, QATTN_FMT_E4M3, false>(p, scale_mode, st);
+    return causal ? launch_attn_v2_t<D, NW, QATTN_FMT_E5M2, true>(p, scale_mode, st) : launch_attn_v2_t<D, NW, QATTN_FMT_E5M2, false>(p, scale_mode, st);
 }
 
 int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (D == 128) return launch_attn_v2_d<128>(p, fmt, causal, scale_mode, st);
-    return QATTN_ERR_UNSUPPORTED_DIM;
+    if (D != 128) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (p.waves == 4) return launch_attn_v2_d<128, 4>(p, fmt, causal, scale_mode, st);
+    return launch_attn_v2_d<128, 8>(p, fmt, causal, scale_mode, st);
 }
 
 }  // namespace qattn

@@ -102,9 +102,14 @@ def test_fused_path_from_16bit_inputs(case):
     qg8, sqg = _native.quant_fp8(q.cuda(), scaling=scaling, fp8_dtype=TDT[fp8])
     kf, skg = _native.quant_fp8(k.cuda(), scaling=scaling, fp8_dtype=TDT[fp8], layout=_native.LAYOUT_KFRAG)
     vf, svg = _native.quant_fp8(v.cuda(), scaling="head-wise", fp8_dtype=TDT[fp8], layout=_native.LAYOUT_VFRAG)
-    out2, lse = _native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype,
-                                              is_causal=causal, scaling=scaling, return_lse=True)
+    out2 = _native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype,
+                                         is_causal=causal, scaling=scaling)
     assert torch.equal(out2, out), "the op and the direct C-ABI sequence must agree bit for bit"
+    # asking for the LSE selects the exact-exponential path (the fast path's row sum is of the quantised P)
+    out3, lse = _native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype,
+                                              is_causal=causal, scaling=scaling, return_lse=True)
+    mx3, _ = err_stats(out_to_f32(out3), ref)
+    assert mx3 < tol_for(ref), mx3
     np.testing.assert_allclose(lse.cpu().numpy(), ref_lse, rtol=0, atol=2e-3)
 
 
