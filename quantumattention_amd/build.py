@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libqattn_hip.so")
-SOURCES = ["qattn_quant.hip", "qattn_attn_v1.hip", "qattn_attn_v2.hip", "qattn_api.hip"]
+SOURCES = ["qattn_quant.hip", "qattn_attn_v1.hip", "qattn_attn_v2.hip", "qattn_attn_v3.hip", "qattn_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-ffp-contract=off", "-Wall", "-Wno-unused-command-line-argument", "-Wno-unused-value", "-Wno-pass-failed"]

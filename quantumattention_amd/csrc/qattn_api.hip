@@ -9,7 +9,8 @@
 
 using namespace qattn;
 
-// Development switch: QATTN_KERNEL_VARIANT=1 selects the first (non-pipelined) kernel structure for A/B runs.
+// Development switch for A/B runs: QATTN_KERNEL_VARIANT = 1 (first, non-pipelined structure), 2 (default for D = 128:
+// 8 waves x 32 rows, pipelined), 3 (experimental: 4 waves x 64 rows; correct but register-allocation bound).
 // QATTN_EXACT_EXP=1 disables the byte-exponential fast path (see qattn_attn_v2.hip).
 static int exact_exp() {
     static int v = -1;
@@ -52,12 +53,13 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     p.out = out; p.lse = lse; p.sq = scale_q; p.sk = scale_k; p.sv = scale_v;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
     const bool use_v1 = (D != 128 || kernel_variant() == 1);
-    p.waves = use_v1 ? kWaves : env_int("QATTN_V2_WAVES", 8);
+    const bool use_v3 = !use_v1 && kernel_variant() == 3;
+    p.waves = (use_v1 || use_v3) ? kWaves : env_int("QATTN_V2_WAVES", 8);  // v1 and v3 workgroups also cover 256 rows
     p.lds_pad = env_int("QATTN_V2_LDS", 0);
     p.dbg = env_int("QATTN_V2_DBG", 0);
     p.dbg_buf = nullptr;
     static unsigned long long* dbg_dev = nullptr;
-    const long n_dbg_waves = (long)B * Hq * ceil_div(Sq, p.waves * kQPerWave) * p.waves;
+    const long n_dbg_waves = (long)B * Hq * ceil_div(Sq, p.waves * kQPerWave) * (use_v3 ? 4 : p.waves);
     if (p.dbg & 16) {
         if (!dbg_dev) (void)hipMalloc(&dbg_dev, sizeof(unsigned long long) * 2 * (1 << 20));
         p.dbg_buf = dbg_dev;
@@ -73,6 +75,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (use_v1) rc = launch_attn_v1(p, D, qk_fmt, is_causal, scale_mode, st);
+    else if (use_v3) rc = launch_attn_v3(p, D, qk_fmt, is_causal, scale_mode, st);
     else rc = launch_attn_v2(p, D, qk_fmt, is_causal, scale_mode, st);
     if (rc != QATTN_OK) return rc;
     if ((p.dbg & 16) && p.dbg_buf) {  // diagnostic build path only: synchronises and prints per-wave sweep statistics

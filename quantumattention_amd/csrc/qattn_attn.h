@@ -78,5 +78,6 @@ __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool cau
 
 int launch_attn_v1(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
+int launch_attn_v3(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 
 }  // namespace qattn
