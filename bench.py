@@ -117,18 +117,14 @@ def main():
 
     # ---- dominant kernel alone (roofline): pre-quantised operands, HIP events on the launch stream
     fp8_dtype = _native.FP8_DTYPE[args.fp8]
-    q8, sq = _native.quant_fp8(q, fp8_dtype=fp8_dtype)
-    kf, sk = _native.quant_fp8(k, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_KFRAG)
-    vf, sv = _native.quant_fp8(v, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_VFRAG)
+    q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype)
 
     def attn_only():
         return _native.fp8_attention_forward(q8, kf, vf, sq, sk, sv, Hkv=H, Skv=S, out_dtype=torch.bfloat16,
                                              is_causal=args.causal)
 
     def quant_only():
-        _native.quant_fp8(q, fp8_dtype=fp8_dtype)
-        _native.quant_fp8(k, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_KFRAG)
-        _native.quant_fp8(v, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_VFRAG)
+        _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype)
 
     def event_time(fn, n):
         for _ in range(5):

@@ -95,6 +95,17 @@ int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale, int B, in
                     int scale_mode, int numerics, int out_layout, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/*
+ * Fused pre-pass of one attention call: quantises q, k and v in ONE amax launch + ONE quantise launch
+ * (q8 row-major, k8 QATTN_LAYOUT_KFRAG, v8 QATTN_LAYOUT_VFRAG; q and k scaled per `scale_mode`, v always head-wise).
+ * Same numerics as three qattn_quant_fp8 calls.  `workspace` needs qattn_quant_qkv_workspace_bytes() bytes.
+ * This is what `_fp8_attention_wrapper` does for its two tensors at nn.py:410-418, plus the build's quantised V.
+ */
+size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv);
+int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8,
+                        float* scale_q, float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D,
+                        int out_fmt, int scale_mode, int numerics, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Re-lay a dense row-major fp8 tensor [B,H,S,D] into QATTN_LAYOUT_KFRAG or QATTN_LAYOUT_VFRAG (byte permutation). */
 int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S, int D, int out_layout, void* stream);
 

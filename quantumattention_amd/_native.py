@@ -24,7 +24,8 @@ FP8_DTYPE = {"e4m3": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}
 
 EXPORTS = (
     "qattn_abi_version", "qattn_strerror", "qattn_check_device", "qattn_fp8_tensor_bytes",
-    "qattn_quant_workspace_bytes", "qattn_quant_fp8", "qattn_pack_fp8", "qattn_fp8_attention_forward",
+    "qattn_quant_workspace_bytes", "qattn_quant_fp8", "qattn_quant_qkv_workspace_bytes", "qattn_quant_qkv_fp8",
+    "qattn_pack_fp8", "qattn_fp8_attention_forward",
 )
 
 _lib = None
@@ -52,6 +53,10 @@ def lib() -> ctypes.CDLL:
     L.qattn_quant_workspace_bytes.argtypes = [i, i, i, i, i]
     L.qattn_quant_fp8.restype = i
     L.qattn_quant_fp8.argtypes = [vp, i, vp, vp, i, i, i, i, i, i, i, i, vp, sz, vp]
+    L.qattn_quant_qkv_workspace_bytes.restype = sz
+    L.qattn_quant_qkv_workspace_bytes.argtypes = [i, i, i]
+    L.qattn_quant_qkv_fp8.restype = i
+    L.qattn_quant_qkv_fp8.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, sz, vp]
     L.qattn_pack_fp8.restype = i
     L.qattn_pack_fp8.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.qattn_fp8_attention_forward.restype = i
@@ -105,6 +110,33 @@ def quant_fp8(x: torch.Tensor, *, scaling: str = "head-wise", fp8_dtype=torch.fl
                                _stream(x))
     _check(rc, "qattn_quant_fp8")
     return out, scale
+
+
+def quant_qkv_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scaling: str = "head-wise",
+                  fp8_dtype=torch.float8_e4m3fn, numerics: str = "compiled"):
+    """Fused pre-pass: (q8 row-major fp8, k_frag, v_frag, scale_q, scale_k, scale_v) in two launches."""
+    assert q.is_cuda and q.dim() == 4 and k.shape == v.shape and q.dtype == k.dtype == v.dtype
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, Hq, Sq, D = q.shape
+    _, Hkv, Skv, _ = k.shape
+    L = lib()
+    mode = SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
+    dev = q.device
+    with torch.cuda.device(dev):
+        q8 = torch.empty((B, Hq, Sq, D), dtype=fp8_dtype, device=dev)
+        kf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
+        vf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
+        sq = torch.empty((B, Hq) if mode == SCALE_HEAD else (B, Hq, Sq), dtype=torch.float32, device=dev)
+        sk = torch.empty((B, Hkv) if mode == SCALE_HEAD else (B, Hkv, Skv), dtype=torch.float32, device=dev)
+        sv = torch.empty((B, Hkv), dtype=torch.float32, device=dev)
+        ws_bytes = L.qattn_quant_qkv_workspace_bytes(B, Hq, Hkv)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        rc = L.qattn_quant_qkv_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), q8.data_ptr(),
+                                   kf.data_ptr(), vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(),
+                                   B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode, NUMERICS[numerics],
+                                   ws.data_ptr(), ws_bytes, _stream(q))
+    _check(rc, "qattn_quant_qkv_fp8")
+    return q8, kf, vf, sq, sk, sv
 
 
 def pack_fp8(x8: torch.Tensor, layout: int) -> torch.Tensor:

@@ -167,6 +167,149 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const uint4* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Fused q/k/v pre-pass: ONE amax launch and ONE quantise launch cover the three tensors (blockIdx.z = tensor).
+// LDS patterns are conflict-free (the first version's byte scatter spent ~90 % of its LDS cycles in bank
+// conflicts, profiles/r01_v1/pmc_summary.json):
+//   ROWMAJOR  no LDS at all: 8-byte coalesced stores.
+//   KFRAG     8-byte writes into the fragment image padded by 16 B per 512 B, linear 16-byte copy-out.
+//   VFRAG     fp8 tile row-major in LDS with a 132-byte row stride, then each thread gathers the 4 keys of an
+//             output dword with ds_read_u8 (4 lanes share a dword = broadcast, 16 banks hit per instruction) and
+//             stores dwords straight to global memory.
+// ---------------------------------------------------------------------------------------------------------
+struct QuantJob {
+    const uint4* x;       // [G, S, D] 16-bit
+    uint4* out;           // fp8 payload
+    float* scale;         // [G] (head) or [G, S] (token)
+    unsigned* amax_bits;  // [G] workspace (head-wise)
+    int G, S, layout, token;
+};
+struct QuantJobs {
+    QuantJob j[3];
+};
+
+template <int IN_FMT>
+__global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, int D, int splits) {
+    const QuantJob& jb = jobs.j[blockIdx.z];
+    if (jb.token || (int)blockIdx.y >= jb.G) return;
+    const long vecs_per_group = (long)jb.S * D / 8;
+    const long g = blockIdx.y;
+    const uint4* xg = jb.x + g * vecs_per_group;
+    const long per = (vecs_per_group + splits - 1) / splits;
+    const long beg = (long)blockIdx.x * per;
+    long end = beg + per;
+    if (end > vecs_per_group) end = vecs_per_group;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    unsigned m0 = 0, m1 = 0;
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        uint4 v = xg[i];
+        unsigned a = v.x & 0x7fff7fffu, b = v.y & 0x7fff7fffu, c = v.z & 0x7fff7fffu, d = v.w & 0x7fff7fffu;
+        u16x2 pa, pb, pc, pd, p0, p1;
+        __builtin_memcpy(&pa, &a, 4); __builtin_memcpy(&pb, &b, 4); __builtin_memcpy(&pc, &c, 4); __builtin_memcpy(&pd, &d, 4);
+        __builtin_memcpy(&p0, &m0, 4); __builtin_memcpy(&p1, &m1, 4);
+        p0 = __builtin_elementwise_max(p0, __builtin_elementwise_max(pa, pb));
+        p1 = __builtin_elementwise_max(p1, __builtin_elementwise_max(pc, pd));
+        __builtin_memcpy(&m0, &p0, 4); __builtin_memcpy(&m1, &p1, 4);
+    }
+    unsigned m = max(max(m0 & 0xffffu, m0 >> 16), max(m1 & 0xffffu, m1 >> 16));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        atomicMax(jb.amax_bits + g, __float_as_uint(load16f<IN_FMT>((unsigned short)m)));
+    }
+}
+
+template <int D, int IN_FMT, int OUT_FMT>
+__global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, int numerics) {
+    constexpr int VPR = D / 8;             // 16-byte input vectors per row
+    constexpr int ITERS = 64 * VPR / 256;  // vectors per thread
+    constexpr int KPAD = 64 * D + (64 * D / 512) * 16;  // KFRAG image + 16 B per 512 B
+    constexpr int VSTRIDE = D + 4;                      // VFRAG staging: fp8 row-major, 132-byte rows for D = 128
+    constexpr int LDS_BYTES = KPAD > 64 * VSTRIDE ? KPAD : 64 * VSTRIDE;
+    __shared__ __attribute__((aligned(16))) unsigned char img[LDS_BYTES];
+    const QuantJob& jb = jobs.j[blockIdx.z];
+    const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int S = jb.S;
+    const int row0 = tile * 64;
+    if (g >= jb.G || row0 >= S) return;
+    const int layout = jb.layout;
+    const bool token = jb.token != 0;
+    const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
+    const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
+    float scale = 1.0f;
+    if (!token) {
+        scale = make_scale(__uint_as_float(jb.amax_bits[g]), inv_qmax, numerics, IN_FMT);
+        if (tile == 0 && tid == 0) jb.scale[g] = scale;
+    }
+    const uint4* xg = jb.x + (long)g * S * VPR;
+    const long Sp = (long)((S + 63) / 64) * 64;
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int vec = it * 256 + tid;
+        const int r = vec / VPR, dv = vec % VPR;
+        const int row = row0 + r;
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (row < S) raw = xg[(long)row * VPR + dv];
+        unsigned short e[8];
+        __builtin_memcpy(e, &raw, 16);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] = load16f<IN_FMT>(e[j]);
+        if (token) {
+            float a = 0.0f;
+            bool nan = false;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a = fmaxf(a, fabsf(f[j])); nan |= (f[j] != f[j]); }
+            unsigned ab = nan ? 0x7fc00000u : __float_as_uint(a);
+#pragma unroll
+            for (int off = VPR / 2; off > 0; off >>= 1) ab = max(ab, (unsigned)__shfl_xor((int)ab, off));
+            scale = make_scale(__uint_as_float(ab), inv_qmax, numerics, IN_FMT);
+            if (dv == 0 && row < S) jb.scale[(long)g * S + row] = scale;
+        }
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float t = round16<IN_FMT>(f[j] / scale);  // IEEE fp32 divide, then the reference's rounding to the input dtype
+            t = t > qmax ? qmax : t;
+            t = t < -qmax ? -qmax : t;
+            q[j] = t;
+        }
+        const int lo = cvt4_fp8<OUT_FMT>(q[0], q[1], q[2], q[3]);
+        const int hi = cvt4_fp8<OUT_FMT>(q[4], q[5], q[6], q[7]);
+        const int d0 = dv * 8;
+        if (layout == QATTN_LAYOUT_ROWMAJOR) {
+            if (row < S) reinterpret_cast<int2*>(jb.out)[((long)g * S + row) * (D / 8) + dv] = make_int2(lo, hi);
+        } else if (layout == QATTN_LAYOUT_KFRAG) {
+            const int o = kfrag_offset<D>(r, d0);
+            *reinterpret_cast<int2*>(img + o + ((o >> 9) << 4)) = make_int2(lo, hi);
+        } else {
+            *reinterpret_cast<int*>(img + r * VSTRIDE + d0) = lo;
+            *reinterpret_cast<int*>(img + r * VSTRIDE + d0 + 4) = hi;
+        }
+    }
+    if (layout == QATTN_LAYOUT_ROWMAJOR) return;
+    __syncthreads();
+    if (layout == QATTN_LAYOUT_KFRAG) {
+        uint4* og = jb.out + ((long)g * Sp + row0) * (D / 16);
+        for (int i = tid; i < 64 * D / 16; i += 256) og[i] = *reinterpret_cast<const uint4*>(img + i * 16 + ((i >> 5) << 4));
+    } else {
+        // output dword n of the chunk: [m:D/32][hh:2][half:2][dl:32][w:4] holds keys 32*half + 8*w + 4*hh + (0..3) at d = 32*m + dl
+        unsigned* og = reinterpret_cast<unsigned*>(jb.out) + ((long)g * Sp + row0) * (D / 4);
+#pragma unroll
+        for (int k = 0; k < 64 * D / 4 / 256; k++) {
+            const int n = k * 256 + tid;
+            const int w = n & 3, dl = (n >> 2) & 31, half = (n >> 7) & 1, hh = (n >> 8) & 1, m = n >> 9;
+            const unsigned char* src = img + (32 * half + 8 * w + 4 * hh) * VSTRIDE + 32 * m + dl;
+            const unsigned b0 = src[0], b1 = src[VSTRIDE], b2 = src[2 * VSTRIDE], b3 = src[3 * VSTRIDE];
+            og[n] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------
 template <int D, int IN_FMT, int OUT_FMT>
@@ -256,5 +399,61 @@ extern "C" int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, i
     if (out_layout == QATTN_LAYOUT_KFRAG) { if (D == 64) PK(64, QATTN_LAYOUT_KFRAG); else if (D == 128) PK(128, QATTN_LAYOUT_KFRAG); else PK(256, QATTN_LAYOUT_KFRAG); }
     else { if (D == 64) PK(64, QATTN_LAYOUT_VFRAG); else if (D == 128) PK(128, QATTN_LAYOUT_VFRAG); else PK(256, QATTN_LAYOUT_VFRAG); }
 #undef PK
+    return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
+}
+
+extern "C" size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0) return 0;
+    return (size_t)B * (Hq + 2 * (size_t)Hkv) * sizeof(unsigned);
+}
+
+template <int D>
+static int launch_quant_multi(const QuantJobs& jobs, int in_fmt, int out_fmt, int numerics, dim3 grid, hipStream_t st) {
+    dim3 block(256);
+    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E4M3) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_BF16, QATTN_FMT_E4M3>), grid, block, 0, st, jobs, numerics);
+    else if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E5M2) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_BF16, QATTN_FMT_E5M2>), grid, block, 0, st, jobs, numerics);
+    else if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E4M3) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_FP16, QATTN_FMT_E4M3>), grid, block, 0, st, jobs, numerics);
+    else if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E5M2) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_FP16, QATTN_FMT_E5M2>), grid, block, 0, st, jobs, numerics);
+    else return QATTN_ERR_UNSUPPORTED_FMT;
+    return QATTN_OK;
+}
+
+extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8,
+                                   float* scale_q, float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv,
+                                   int D, int out_fmt, int scale_mode, int numerics, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    if (!q || !k || !v || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
+    if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (out_fmt != QATTN_FMT_E4M3 && out_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    const size_t need = qattn_quant_qkv_workspace_bytes(B, Hq, Hkv);
+    if (!workspace || workspace_bytes < need) return QATTN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* ws = (unsigned*)workspace;
+    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return QATTN_ERR_LAUNCH;
+    const int tok = scale_mode == QATTN_SCALE_TOKEN;
+    QuantJobs jobs;
+    jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok};
+    jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + (size_t)B * Hq, B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok};
+    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + (size_t)B * (Hq + Hkv), B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0};
+    const int Gmax = B * (Hq > Hkv ? Hq : Hkv), Smax = Sq > Skv ? Sq : Skv;
+    {
+        const long vecs = (long)Smax * D / 8;
+        int splits = (int)((vecs + 4095) / 4096);
+        if (splits < 1) splits = 1;
+        if (splits > 64) splits = 64;
+        dim3 grid(splits, Gmax, 3), block(256);
+        if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, splits);
+        else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, splits);
+    }
+    dim3 grid((Smax + 63) / 64, Gmax, 3);
+    int rc;
+    if (D == 64) rc = launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, grid, st);
+    else if (D == 128) rc = launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, grid, st);
+    else rc = launch_quant_multi<256>(jobs, in_fmt, out_fmt, numerics, grid, st);
+    if (rc != QATTN_OK) return rc;
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }

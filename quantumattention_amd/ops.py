@@ -80,12 +80,8 @@ def fp8_quant_attention_forward(
     fragment layouts, then the attention kernel runs -- what `_fp8_attention_wrapper` (nn.py:394-430) does in the
     reference through Inductor, without the intermediate row-major K copy."""
     fp8_dtype = _native.FP8_DTYPE[fp8_format]
-    q8, sq = _native.quant_fp8(query, scaling=scaling_method, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_ROWMAJOR,
-                               numerics=numerics)
-    k_frag, sk = _native.quant_fp8(key, scaling=scaling_method, fp8_dtype=fp8_dtype, layout=_native.LAYOUT_KFRAG,
-                                   numerics=numerics)
-    v_frag, sv = _native.quant_fp8(value, scaling="head-wise", fp8_dtype=fp8_dtype, layout=_native.LAYOUT_VFRAG,
-                                   numerics=numerics)
+    q8, k_frag, v_frag, sq, sk, sv = _native.quant_qkv_fp8(query, key, value, scaling=scaling_method,
+                                                           fp8_dtype=fp8_dtype, numerics=numerics)
     return _native.fp8_attention_forward(
         q8, k_frag, v_frag, sq, sk, sv, Hkv=key.shape[1], Skv=key.shape[2], out_dtype=value.dtype,
         is_causal=is_causal, scaling=scaling_method, sm_scale=0.0 if scale is None else float(scale))

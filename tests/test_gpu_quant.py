@@ -73,3 +73,31 @@ def test_quant_eager_numerics_and_constant_tensor():
     z = torch.zeros((1, 1, 64, 64), dtype=torch.float16)
     x8, s = _native.quant_fp8(z.cuda())
     assert not bits8(x8).any() and float(s[0, 0]) == float(np.float32(1.1920928955078125e-07))
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2, 64, 64, 64), (2, 4, 2, 200, 333, 128), (1, 2, 2, 1000, 1000, 256), (1, 1, 1, 4096, 4096, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fp8", ["e4m3", "e5m2"])
+@pytest.mark.parametrize("scaling", ["head-wise", "token-wise"])
+def test_fused_qkv_prepass_matches_oracle_bit_exact(shape, dtype, fp8, scaling):
+    """qattn_quant_qkv_fp8: one amax launch + one quantise launch for q (row-major), k (KFRAG), v (VFRAG)."""
+    B, Hq, Hkv, Sq, Skv, D = shape
+    torch.manual_seed(3)
+    q = (torch.randn(B, Hq, Sq, D) * 2).to(dtype)
+    k = (torch.randn(B, Hkv, Skv, D) * torch.rand(B, Hkv, 1, 1) * 4).to(dtype)
+    v = (torch.randn(B, Hkv, Skv, D) * 0.5).to(dtype)
+    m = "head" if scaling == "head-wise" else "token"
+    q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q.cuda(), k.cuda(), v.cuda(), scaling=scaling, fp8_dtype=TDT[fp8])
+    for got8, gots, x, mode, layout, (H, S) in (
+        (q8, sq, q, m, _native.LAYOUT_ROWMAJOR, (Hq, Sq)),
+        (kf, sk, k, m, _native.LAYOUT_KFRAG, (Hkv, Skv)),
+        (vf, sv, v, "head", _native.LAYOUT_VFRAG, (Hkv, Skv)),
+    ):
+        ref8, refs = oracle.quantize_fp8(bits16(x), fmt16(dtype), mode, FMT[fp8], "compiled")
+        np.testing.assert_array_equal(gots.cpu().numpy().view(np.uint32), refs.view(np.uint32))
+        got = bits8(got8)
+        if layout != _native.LAYOUT_ROWMAJOR:
+            full = unpack_frag(got, layout, B, H, S, D)
+            assert not full[:, :, S:, :].any(), "padding rows must be zero"
+            got = full[:, :, :S, :]
+        np.testing.assert_array_equal(got, ref8)
