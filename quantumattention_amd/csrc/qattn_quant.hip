@@ -230,11 +230,14 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     constexpr int VSTRIDE = D + 4;                      // VFRAG staging: fp8 row-major, 132-byte rows for D = 128
     constexpr int LDS_BYTES = KPAD > 64 * VSTRIDE ? KPAD : 64 * VSTRIDE;
     __shared__ __attribute__((aligned(16))) unsigned char img[LDS_BYTES];
-    const QuantJob& jb = jobs.j[blockIdx.z];
-    const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    // walk the tensors, heads and tiles in the REVERSE order of the amax pass: the amax pass streamed 3 tensors
+    // through the 256 MiB Infinity Cache, so its last ~256 MiB are the bytes most likely still on-die
+    const QuantJob& jb = jobs.j[2 - blockIdx.z];
+    const int tid = threadIdx.x;
     const int S = jb.S;
+    const int g = jb.G - 1 - (int)blockIdx.y, tile = (S + 63) / 64 - 1 - (int)blockIdx.x;
     const int row0 = tile * 64;
-    if (g >= jb.G || row0 >= S) return;
+    if (g < 0 || tile < 0) return;
     const int layout = jb.layout;
     const bool token = jb.token != 0;
     const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;

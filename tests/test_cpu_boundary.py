@@ -1,0 +1,106 @@
+"""CPU-only tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/qattn.h declares
+(no compute calls without a GPU), argument validation returns the documented codes, and the Python call surface
+mirrors the reference's (names, signatures, error behaviour, CPU fallback = BASELINE config 1)."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import quantumattention_amd as qa
+from quantumattention_amd import _native
+from tests.conftest import GOLDEN, ROOT
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "qattn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qattn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    names = _header_functions()
+    assert set(names) == set(_native.EXPORTS), (names, _native.EXPORTS)
+    L = ctypes.CDLL(_native.LIB_PATH)
+    for n in names:
+        assert getattr(L, n) is not None, n
+    lib = _native.lib()
+    assert lib.qattn_abi_version() == _native.ABI_VERSION == 1
+
+
+def test_abi_size_queries_and_error_codes_need_no_gpu():
+    L = _native.lib()
+    assert L.qattn_fp8_tensor_bytes(_native.LAYOUT_ROWMAJOR, 4, 32, 4096, 128) == 4 * 32 * 4096 * 128
+    assert L.qattn_fp8_tensor_bytes(_native.LAYOUT_KFRAG, 1, 2, 200, 128) == 1 * 2 * 256 * 128  # padded to 64 keys
+    assert L.qattn_fp8_tensor_bytes(_native.LAYOUT_VFRAG, 1, 2, 64, 64) == 2 * 64 * 64
+    assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_HEAD) == 4 * 32 * 4
+    assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_TOKEN) == 0
+    assert L.qattn_quant_qkv_workspace_bytes(4, 32, 8) == 4 * (32 + 16) * 4
+    for code in range(0, -7, -1):
+        assert L.qattn_strerror(code)
+    assert b"unknown" in L.qattn_strerror(-99)
+    # validation happens before any HIP call: NULL pointers / bad dims are rejected on a CPU-only box too
+    assert L.qattn_fp8_attention_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 128, 0, 0, 2, 0, 0, 0.0, None) == -1
+    assert L.qattn_quant_fp8(None, 2, None, None, 1, 1, 1, 128, 0, 0, 0, 0, None, 0, None) == -1
+    assert L.qattn_pack_fp8(None, None, 1, 1, 1, 128, 1, None) == -1
+    one = ctypes.c_void_p(16)  # any non-NULL pointer: dimension checks come first
+    assert L.qattn_fp8_attention_forward(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 96, 0, 0, 2, 0, 0, 0.0, None) == -2
+    assert L.qattn_fp8_attention_forward(one, one, one, one, None, one, one, None, 1, 3, 2, 8, 8, 128, 0, 0, 2, 0, 0, 0.0, None) == -2
+    assert L.qattn_fp8_attention_forward(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 128, 2, 2, 2, 0, 0, 0.0, None) == -3
+
+
+def test_public_names_and_signatures_mirror_the_reference():
+    # src/quantum_attn/__init__.py:23-31
+    assert qa.__all__ == [
+        "attn_func", "attn_func_with_fallback", "dynamically_quantize_fp8", "fp8_attn_func",
+        "fp8_attn_func_with_fallback", "fp8_token_wise_attn_func", "fp8_token_wise_attn_func_with_fallback",
+    ]
+    sdpa = ["query", "key", "value", "attn_mask", "dropout_p", "is_causal", "scale"]
+    assert list(inspect.signature(qa.attn_func).parameters) == sdpa                                   # interface.py:41-50
+    assert list(inspect.signature(qa.fp8_attn_func).parameters) == sdpa + ["scale_q", "scale_k", "scaling_method"]  # :101-113
+    assert list(inspect.signature(qa.fp8_token_wise_attn_func).parameters) == sdpa + ["scale_q", "scale_k"]         # :179-190
+    assert list(inspect.signature(qa.nn.can_use_attention).parameters) == sdpa + ["scaling_method"]  # nn.py:282-292
+    for flag in ("skip_supported_check", "force_eager_fallback"):                                   # config.py:27-28
+        assert hasattr(qa.config.attention, flag)
+    with qa.config.patch({"attention.skip_supported_check": True}):                                 # config.py:34-41
+        q = torch.randn(1, 2, 16, 64, dtype=torch.bfloat16)
+        assert qa.nn.can_use_attention(q, q, q) == (True, "")
+
+
+def test_cpu_plumbing_matches_reference_golden_config1():
+    """BASELINE config 1 (B1 H2 S128 D64, CPU): *_with_fallback == F.sdpa, bit for bit, and equal to the reference's
+    own output stored in the golden file (interface.py:62-98)."""
+    z = np.load(os.path.join(GOLDEN, "c1_b1h2s128d64_bf16_s0.npz"))
+    to_t = lambda b: torch.from_numpy(b.view(np.int16).copy()).view(torch.bfloat16)
+    q, k, v = to_t(z["q"]), to_t(z["k"]), to_t(z["v"])
+    ref = to_t(z["fallback_full"])
+    torch.set_num_threads(4)
+    for fn in (qa.attn_func_with_fallback, qa.fp8_attn_func_with_fallback, qa.fp8_token_wise_attn_func_with_fallback):
+        out = fn(q, k, v)
+        assert torch.equal(out, torch.nn.functional.scaled_dot_product_attention(q, k, v))
+        assert (out.float() - ref.float()).abs().max() <= 2.0 ** -8  # same aten kernel; thread partition may differ
+    ok, reason = qa.nn.can_use_attention(q, k, v, scaling_method="head-wise")
+    assert not ok and "CUDA device" in reason  # same first reason as the reference (tests/golden/can_use_attention_cpu.txt)
+    assert "CUDA device" in open(os.path.join(GOLDEN, "can_use_attention_cpu.txt")).read()
+    with pytest.raises(ValueError):
+        qa.fp8_attn_func(q, k, v)  # nn.py:461-462: ValueError(reason) on unsupported input
+    with pytest.raises(ValueError):
+        qa.attn_func(q, k, v)
+
+
+def test_eager_quantiser_definition_on_cpu_matches_golden_eager_numerics():
+    z = np.load(os.path.join(GOLDEN, "c1_b1h2s128d64_bf16_s0.npz"))
+    q = torch.from_numpy(z["q"].view(np.int16).copy()).view(torch.bfloat16)
+    q8, s = qa.dynamically_quantize_fp8(q, reduction_dim=[2, 3])  # CPU tensor -> eager torch definition (nn.py:14-19)
+    np.testing.assert_array_equal(q8.view(torch.uint8).numpy(), z["q8_head_eager"])
+    np.testing.assert_array_equal(s.numpy(), z["sq_head_eager"])
+
+
+def test_native_binding_fails_loudly_without_the_library(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
+        _native.lib()
