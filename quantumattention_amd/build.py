@@ -16,6 +16,9 @@ BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libqattn_hip.so")
 SOURCES = ["qattn_quant.hip", "qattn_attn_v1.hip", "qattn_attn_v2.hip", "qattn_attn_v3.hip", "qattn_api.hip"]
 ARCH = "gfx950"
+# one-wave-per-SIMD kernels (up to 512 registers): keep MFMA results that the VALU reads in architectural VGPRs instead
+# of the default AGPR-form MFMAs, which cost ~146 v_accvgpr copies per iteration
+EXTRA_FLAGS = {"qattn_attn_v3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-ffp-contract=off", "-Wall", "-Wno-unused-command-line-argument", "-Wno-unused-value", "-Wno-pass-failed"]
 
@@ -45,7 +48,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False) 
         o = os.path.join(BUILD, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)

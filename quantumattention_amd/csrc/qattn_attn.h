@@ -10,8 +10,8 @@ constexpr int kQPerWave = 32;                // query rows per wave (MFMA N)
 constexpr int kQPerWG = kWaves * kQPerWave;  // 256
 constexpr float kPShift = 5.0f;              // P' = P * 2^5 keeps small probabilities above the e4m3 subnormals
 constexpr float kRescaleThr = 3.0f;          // log2 units: P' <= 2^(5+3) = 256 < 448 (e4m3 max)
-constexpr float kPShiftByte = 7.0f;          // byte-exponential mode: P' = P * 2^7 (keeps bytes out of the e4m3 subnormals,
-constexpr float kRescaleThrByte = 1.0f;      //   where byte ~ 8x+56 is not an exponential), P' <= 2^8 -> byte <= 120 < 0x7e
+constexpr float kPShiftByte = 5.0f;          // byte-exponential mode: P' = P * 2^5 and a deferred-rescale threshold of 3:
+constexpr float kRescaleThrByte = 3.0f;      //   P' <= 2^8 -> byte <= 120 < 0x7e; a tighter threshold (1) made the fix-up frequent
 constexpr float kByteBias = -0.3f;           // centres the (1+m/8 >= 2^(m/8)) mantissa error of the byte exponential
 constexpr int kTwoTermKeys = 1024;           // rows that see fewer keys than this use hi+lo (two-term) fp8 P
 
