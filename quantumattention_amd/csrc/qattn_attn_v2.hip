@@ -69,6 +69,8 @@ struct WaveState {
     float l_run;   // this lane's partial row sum of P' (exact-exp mode)
     v16f l16;      // BYTE mode: every register = the full row sum of the quantised P', accumulated by a ones-row MFMA
     float c;       // scale_q*scale_k*sm_scale*log2(e)
+    unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
+    unsigned long long tlast;
 };
 
 template <int QK_FMT, int D>
@@ -166,6 +168,17 @@ __device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, floa
 }
 
 #define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define QATTN2_STAMP(I)                                                                                          \
+    do {                                                                                                        \
+        if (ABL & 16) {                                                                                         \
+            unsigned long long t_;                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            st.seg[I] += t_ - st.tlast;                                                                         \
+            st.tlast = t_;                                                                                      \
+        }                                                                                                       \
+    } while (0)
 #define QATTN_SM_GROUP(FIRST, SX, J, MC, W, SEED)                                   \
     do {                                                                            \
         if (ABL & 4) break;                                                         \
@@ -235,6 +248,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     v8i kb = LDSF(kbuf + (2 << 11));
     QATTN_SM_GROUP(false, sc0, 2, mc, 2, pc[1]);
     QATTN_SLOT_FENCE();
+    QATTN2_STAMP(1);
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
     if (BYTE) {
         v8i ones;
@@ -272,6 +286,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     }
     float ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     QATTN_SLOT_FENCE();
+    QATTN2_STAMP(2);
     // rare fix-up: some row's max grew by more than the threshold (always on the first chunk: m_run = -1e30):
     // rescale everything accumulated so far (O and the row sum include chunk t-2) and redo this chunk's exponentials
     if (__builtin_expect(__any((mx - st.m_run) * c > THR) != 0, 0)) {
@@ -296,6 +311,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
         ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
     st.l_run += ls;
+    QATTN2_STAMP(3);
 }
 
 // The KV sweep of one wave.  Returns with st.o / st.l_run / st.m_run final.
@@ -327,24 +343,37 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     stage_write<D, NW>(sr, smem, wave, lane);
     load_for(1);
     // every iteration t (all T of them, on every wave) starts here
+    // Staging of stage(t+1) / loads of stage(t+2) may happen anywhere inside iteration t (the slot it overwrites was
+    // last read in iteration t-1, which every wave finished before barrier(t)).  Waves 0-3 do it right after the
+    // barrier, waves 4-7 at the end of the iteration: the two waves of a SIMD leave the barrier together, and this
+    // de-phases their non-MFMA work so one's staging overlaps the other's matrix slots.
+    const bool stage_early = true;  // (de-phasing waves 4-7 to stage at the end of the iteration measured 7 % slower)
+    auto do_stage = [&](int t) {
+        if (ABL & 1) return;
+        if (t + 1 < T) stage_write<D, NW>(sr, smem + ((t + 1) % kStagesV2) * STAGE, wave, lane);  // waits vmcnt for sr
+        if (t + 2 < T) load_for(t + 2);
+    };
     auto sync_iter = [&](int t) -> const unsigned char* {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of stage(t) are in LDS
+        // this wave's ds_writes of stage(t) must be in LDS before it signals; the 4 newest LDS ops are the
+        // cross-barrier V-fragment reads (2 x 2 ds_read_b128) and may stay in flight
+        if (t > 0 && !stage_early) { do_stage(t - 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
-        if (!(ABL & 1)) {
-            if (t + 1 < T) stage_write<D, NW>(sr, smem + ((t + 1) % kStagesV2) * STAGE, wave, lane);  // waits vmcnt for sr
-            if (t + 2 < T) load_for(t + 2);
-        }
+        if (stage_early) do_stage(t);
         return smem + (t % kStagesV2) * STAGE + frag_lane_off;
     };
     auto full = [&](auto par_tag, int t) {
         constexpr int PAR = decltype(par_tag)::value;
         const unsigned char* kbuf = sync_iter(t);
         const unsigned char* vprev = smem + ((t - 1) % kStagesV2) * STAGE + CH + frag_lane_off;
+        QATTN2_STAMP(0);
         prep_scores<CAUSAL, TOKEN>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL>(st, kbuf, vprev, kbuf + CH, qbuf);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    for (int i = 0; i < 6; i++) st.seg[i] = 0;
+    st.tlast = __builtin_amdgcn_s_memtime();
 
     // t = 0: QK(0) only
     {
@@ -390,6 +419,7 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // causal: waves whose rows end earlier keep the workgroup's barrier / DMA cadence until the last wave is done
     for (; t < T; ++t) sync_iter(t);
+    if (!stage_early) do_stage(T - 1);  // no-op (nothing left to stage); keeps the protocol symmetric
 }
 
 // QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
@@ -467,6 +497,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
             const long wid = (long)blockIdx.x * NW + wave;
             p.dbg_buf[2 * wid] = t1 - dbg_t0;
             p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
+            if ((ABL & 16) && wid < 64) {
+                unsigned long long* segout = p.dbg_buf + 2 * (1 << 19) + wid * 8;
+                for (int i = 0; i < 6; i++) segout[i] = st.seg[i];
+            }
         }
     }
     const float m_run = st.m_run, l_run = st.l_run;
@@ -546,8 +580,8 @@ static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st)
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, 0, p.nqb);                             \
             return QATTN_OK;                                                                                       \
         }
-        switch ((p.dbg >> 8) == 0 ? 0 : (p.dbg & 15)) {
-            QATTN_ABL_CASE(1) QATTN_ABL_CASE(2) QATTN_ABL_CASE(4) QATTN_ABL_CASE(8) QATTN_ABL_CASE(12) QATTN_ABL_CASE(15) QATTN_ABL_CASE(3) QATTN_ABL_CASE(11)
+        switch ((p.dbg & 32) ? 16 : (p.dbg & 15)) {
+            QATTN_ABL_CASE(16) QATTN_ABL_CASE(1) QATTN_ABL_CASE(2) QATTN_ABL_CASE(4) QATTN_ABL_CASE(8) QATTN_ABL_CASE(12) QATTN_ABL_CASE(15) QATTN_ABL_CASE(3) QATTN_ABL_CASE(11)
             default: break;
         }
 #undef QATTN_ABL_CASE
