@@ -65,6 +65,7 @@ struct WaveState {
     v8i p[2];               // P^T (e4m3) ping-pong: p[t&1] holds chunk t
     v8i pl[TWO ? 2 : 1];    // low term of the two-term split (unused when !TWO)
     v8i vpre[2];            // V fragments (row blocks 0,1) of the NEXT iteration's PV, read one iteration ahead
+    v8i qreg[2];            // Q^T fragments kept in registers (QREG builds); otherwise re-read from their LDS parking
     float m_run;   // running max of the raw scores
     float l_run;   // this lane's partial row sum of P' (exact-exp mode)
     v16f l16;      // BYTE mode: every register = the full row sum of the quantised P', accumulated by a ones-row MFMA
@@ -195,9 +196,9 @@ __device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, floa
 // bandwidth, are the scarce resource at two waves per SIMD).
 //   kbuf  : stage(t),   K part  (+ lane offset)      vprev : stage(t-1), V part = V(t-2)
 //   vnext : stage(t),   V part = V(t-1) (prefetch for the next iteration)
-template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0>
+template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, typename Stage>
 __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const unsigned char* kbuf, const unsigned char* vprev,
-                                          const unsigned char* vnext, const unsigned char* qbuf) {
+                                          const unsigned char* vnext, const unsigned char* qbuf, Stage&& stage) {
     static_assert(D == 128, "hand-placed slots are written for D = 128");
     // ABL (timing-only ablations, results wrong): 4 = no softmax VALU, 8 = no LDS fragment reads (operands = a fixed register set)
     auto LDSF = [&](const unsigned char* ptr) -> v8i { if (ABL & 8) return st.vpre[0]; return lds_read_frag(ptr); };
@@ -249,6 +250,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     QATTN_SM_GROUP(false, sc0, 2, mc, 2, pc[1]);
     QATTN_SLOT_FENCE();
     QATTN2_STAMP(1);
+    stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
     if (BYTE) {
         v8i ones;
@@ -315,7 +317,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
 }
 
 // The KV sweep of one wave.  Returns with st.o / st.l_run / st.m_run final.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false>
 __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt) {
@@ -353,22 +355,23 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         if (t + 1 < T) stage_write<D, NW>(sr, smem + ((t + 1) % kStagesV2) * STAGE, wave, lane);  // waits vmcnt for sr
         if (t + 2 < T) load_for(t + 2);
     };
-    auto sync_iter = [&](int t) -> const unsigned char* {
+    auto sync_iter = [&](int t, bool in_step = false) -> const unsigned char* {
         // this wave's ds_writes of stage(t) must be in LDS before it signals; the 4 newest LDS ops are the
         // cross-barrier V-fragment reads (2 x 2 ds_read_b128) and may stay in flight
         if (t > 0 && !stage_early) { do_stage(t - 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
-        if (stage_early) do_stage(t);
+        if (stage_early && !in_step) do_stage(t);
         return smem + (t % kStagesV2) * STAGE + frag_lane_off;
     };
     auto full = [&](auto par_tag, int t) {
         constexpr int PAR = decltype(par_tag)::value;
-        const unsigned char* kbuf = sync_iter(t);
+        const unsigned char* kbuf = sync_iter(t, true);
         const unsigned char* vprev = smem + ((t - 1) % kStagesV2) * STAGE + CH + frag_lane_off;
         QATTN2_STAMP(0);
         prep_scores<CAUSAL, TOKEN>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
-        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL>(st, kbuf, vprev, kbuf + CH, qbuf);
+        auto stage = [&]() { do_stage(t); };
+        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG>(st, kbuf, vprev, kbuf + CH, qbuf, stage);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -490,7 +493,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     st.c = c;
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
-    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt);
+    constexpr bool QREG = !TWO && !TOKEN && !CAUSAL;  // variants with register headroom keep Q^T in registers
+    if (QREG) { st.qreg[0] = lds_read_frag(qbuf); st.qreg[1] = lds_read_frag(qbuf + (1 << 11)); }
+    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt);
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
