@@ -160,7 +160,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collectives"},
             "frac_of_fp8_mfma_peak": value / (FP8_PEAK_TFLOPS * world),
             "attn_kernel_ms": attn_ms, "quant_prepass_ms": quant_ms,
-            "roofline": {"kernel": "attn_fwd_kernel<128,e4m3>", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "qattn::attn_fwd_kernel_v2<128,8,e4m3,e4m3,...> (fused QK^T/softmax/PV)", "bound": "mfma", "achieved": achieved,
                          "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP8_PEAK_TFLOPS,
                          "traffic": traffic},
         }
