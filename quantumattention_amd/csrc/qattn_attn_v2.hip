@@ -28,7 +28,8 @@
 
 namespace qattn {
 
-constexpr int kStagesV2 = 3;
+constexpr int kSyncEvery = 2;                   // waves synchronise every kSyncEvery 64-key iterations
+constexpr int kStagesV2 = 2 * kSyncEvery + 1;   // ring slots: G live + G being filled + the previous V stage
 
 // K/V staging through registers (issue early / write late): LDS-DMA pieces measured ~300 issue cycles each inside
 // this loop (profiles/r01_ablation.md), plain global_load_dwordx4 + ds_write_b128 a few tens.
@@ -57,6 +58,23 @@ __device__ __forceinline__ void stage_write(const StageRegs<D, NW>& sr, unsigned
         *reinterpret_cast<v4i*>(lds_stage + r * (NW * 1024) + (wave << 10) + (lane << 4)) = sr.r[r];
 }
 
+// LDS-DMA copy of one stage image [K chunk | V chunk]: every wave-instruction moves 1 KiB (64 lanes x 16 B), linear.
+template <int D, int NW>
+__device__ __forceinline__ void stage_dma(const unsigned char* ksrc, const unsigned char* vsrc, unsigned char* lds_stage,
+                                          int wave, int lane) {
+    constexpr int CH = 64 * D;
+#pragma unroll
+    for (int r = 0; r < StageRegs<D, NW>::ROUNDS; r++) {
+        const int o = r * (NW * 1024) + (wave << 10);
+        const unsigned char* ubase = o < CH ? ksrc + o : vsrc + (o - CH);  // wave-uniform: make it provably so (saddr form)
+        const unsigned long long ub = (unsigned long long)ubase;
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)ub), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+        const unsigned char* src = (const unsigned char*)(((unsigned long long)hi32 << 32) | lo32) + (lane << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_stage + o), 16, 0, 0);
+    }
+}
+
 template <int D, bool TWO, bool BYTE>
 struct WaveState {
     static constexpr int MB = D / 32;
@@ -65,7 +83,6 @@ struct WaveState {
     v8i p[2];               // P^T (e4m3) ping-pong: p[t&1] holds chunk t
     v8i pl[TWO ? 2 : 1];    // low term of the two-term split (unused when !TWO)
     v8i vpre[2];            // V fragments (row blocks 0,1) of the NEXT iteration's PV, read one iteration ahead
-    v8i qreg[2];            // Q^T fragments kept in registers (QREG builds); otherwise re-read from their LDS parking
     float m_run;   // running max of the raw scores
     float l_run;   // this lane's partial row sum of P' (exact-exp mode)
     v16f l16;      // BYTE mode: every register = the full row sum of the quantised P', accumulated by a ones-row MFMA
@@ -331,39 +348,35 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         st.pl[0][w] = 0;
         if (TWO) st.pl[TWO ? 1 : 0][w] = 0;
     }
-    // Ring protocol (3 stages, stage(t) = {K(t), V(t-1)} lives in slot t%3):
-    //   iteration t:  barrier(t)  ->  ds_write the registers holding stage(t+1) (loaded during iteration t-1) into
-    //   slot (t+1)%3 (its old content, stage(t-2), was last read in iteration t-1)  ->  issue the global loads of
-    //   stage(t+2)  ->  compute on stage(t) [K] and stage(t-1) [V].  barrier(t+1) publishes stage(t+1).
-    StageRegs<D, NW> sr;
-    auto load_for = [&](int t) {
+    // Ring protocol: stage(t) = {K(t), V(t-1)} lives in slot t % kStagesV2 and is filled by LDS-DMA.  Waves synchronise
+    // only every G = kSyncEvery iterations: barrier(t), t % G == 0, publishes stages t .. t+G-1 (DMA issued at iteration
+    // t-G, waited with vmcnt(0) just before the barrier), after which every wave issues the DMA of stages t+G .. t+2G-1.
+    // Between barriers a wave runs G 64-key iterations freely, so the two waves of a SIMD drift apart instead of being
+    // re-aligned every chunk.  Slots live during iterations t .. t+G-1: stages t-1 (V of PV) .. t+G-1; being written:
+    // t+G .. t+2G-1  ->  2G+1 distinct slots.
+    auto dma_for = [&](int t) {
         const int kc = min(t, p.nchunks - 1), vc = min(max(t - 1, 0), p.nchunks - 1);  // stage(t) = {K(t), V(t-1)}
-        stage_load<D, NW>(sr, kg + (long)kc * CH, vg + (long)vc * CH, wave, lane);
+        stage_dma<D, NW>(kg + (long)kc * CH, vg + (long)vc * CH, smem + (t % kStagesV2) * STAGE, wave, lane);
     };
-    // prologue: stage(0) straight into LDS, stage(1) left in flight in the registers
-    load_for(0);
-    stage_write<D, NW>(sr, smem, wave, lane);
-    load_for(1);
-    // every iteration t (all T of them, on every wave) starts here
-    // Staging of stage(t+1) / loads of stage(t+2) may happen anywhere inside iteration t (the slot it overwrites was
-    // last read in iteration t-1, which every wave finished before barrier(t)).  Waves 0-3 do it right after the
-    // barrier, waves 4-7 at the end of the iteration: the two waves of a SIMD leave the barrier together, and this
-    // de-phases their non-MFMA work so one's staging overlaps the other's matrix slots.
-    const bool stage_early = true;  // (de-phasing waves 4-7 to stage at the end of the iteration measured 7 % slower)
-    auto do_stage = [&](int t) {
-        if (ABL & 1) return;
-        if (t + 1 < T) stage_write<D, NW>(sr, smem + ((t + 1) % kStagesV2) * STAGE, wave, lane);  // waits vmcnt for sr
-        if (t + 2 < T) load_for(t + 2);
-    };
+#pragma unroll
+    for (int g = 0; g < kSyncEvery; g++)
+        if (g < T) dma_for(g);
     auto sync_iter = [&](int t, bool in_step = false) -> const unsigned char* {
-        // this wave's ds_writes of stage(t) must be in LDS before it signals; the 4 newest LDS ops are the
-        // cross-barrier V-fragment reads (2 x 2 ds_read_b128) and may stay in flight
-        if (t > 0 && !stage_early) { do_stage(t - 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
-        if (stage_early && !in_step) do_stage(t);
+        (void)in_step;
+        if (t % kSyncEvery == 0) {
+            wait_vmcnt<0>();  // this wave's pieces of stages t .. t+G-1 have landed
+            if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+            if (!(ABL & 1)) {
+#pragma unroll
+                for (int g = 0; g < kSyncEvery; g++)
+                    if (t + kSyncEvery + g < T) dma_for(t + kSyncEvery + g);
+            }
+        } else {
+            asm volatile("s_nop 0" ::: "memory");  // keeps the iterations of a group separate scheduling regions
+        }
         return smem + (t % kStagesV2) * STAGE + frag_lane_off;
     };
+    auto do_stage = [&](int) {};
     auto full = [&](auto par_tag, int t) {
         constexpr int PAR = decltype(par_tag)::value;
         const unsigned char* kbuf = sync_iter(t, true);
@@ -400,29 +413,34 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         (void)sync_iter(t);
         const unsigned char* vprev = smem + ((t - 1) % kStagesV2) * STAGE + CH + frag_lane_off;
         const v8i fc = lds_read_frag(vprev + (2 << 11)), fd = lds_read_frag(vprev + (3 << 11));
-        const v8i& pp = (t & 1) ? st.p[1] : st.p[0];
-        const v8i& ppl = (TWO && (t & 1)) ? st.pl[TWO ? 1 : 0] : st.pl[0];
-        st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], pp, st.o[0]);
-        st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], pp, st.o[1]);
-        st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, pp, st.o[2]);
-        st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, pp, st.o[3]);
-        if (TWO) {
-            st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], ppl, st.o[0]);
-            st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], ppl, st.o[1]);
-            st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
-            st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
-        }
-        if (BYTE) {
-            v8i ones;
+        // two fully static copies: any run-time choice between st.p[0] and st.p[1] (even by value) ends up as a pointer
+        // phi that keeps the P registers in scratch memory
+        auto tail = [&](auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            const v8i& pp = st.p[PAR];
+            const v8i& ppl = st.pl[TWO ? PAR : 0];
+            st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], pp, st.o[0]);
+            st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], pp, st.o[1]);
+            st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, pp, st.o[2]);
+            st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, pp, st.o[3]);
+            if (TWO) {
+                st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], ppl, st.o[0]);
+                st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], ppl, st.o[1]);
+                st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
+                st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
+            }
+            if (BYTE) {
+                v8i ones;
 #pragma unroll
-            for (int w = 0; w < 8; w++) ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;
-            st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(ones, pp, st.l16);
-        }
+                for (int w = 0; w < 8; w++) ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;
+                st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(ones, pp, st.l16);
+            }
+        };
+        if (t & 1) tail(P1{}); else tail(P0{});
         ++t;
     }
     // causal: waves whose rows end earlier keep the workgroup's barrier / DMA cadence until the last wave is done
     for (; t < T; ++t) sync_iter(t);
-    if (!stage_early) do_stage(T - 1);  // no-op (nothing left to stage); keeps the protocol symmetric
 }
 
 // QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
@@ -493,8 +511,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     st.c = c;
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
-    constexpr bool QREG = !TWO && !TOKEN && !CAUSAL;  // variants with register headroom keep Q^T in registers
-    if (QREG) { st.qreg[0] = lds_read_frag(qbuf); st.qreg[1] = lds_read_frag(qbuf + (1 << 11)); }
+    constexpr bool QREG = false;  // (Q^T in registers gained 1-3 % with register staging; with the 5-slot DMA ring the headroom is gone)
     kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt);
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
