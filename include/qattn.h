@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define QATTN_ABI_VERSION 1
+#define QATTN_ABI_VERSION 2
 
 /* element formats */
 #define QATTN_FMT_E4M3 0 /* OCP float8_e4m3fn  (torch.float8_e4m3fn) */
@@ -55,6 +55,12 @@ extern "C" {
 #define QATTN_LAYOUT_ROWMAJOR 0
 #define QATTN_LAYOUT_KFRAG 1
 #define QATTN_LAYOUT_VFRAG 2
+/* fragment layouts of a 16-bit (bf16/fp16) K or V tensor for the 16-bit sibling path (16-byte pieces of 8 elements):
+ *   QATTN_LAYOUT_K16FRAG chunk = [t:2][s:D/16][hh:2][key:32][8 elts], piece = K[64c + 32t + key][16s + 8hh + (0..7)]
+ *   QATTN_LAYOUT_V16FRAG chunk = [m:D/32][t:2][s:2][hh:2][d:32][8 elts],
+ *                        element j of a piece = V[64c + 32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]               */
+#define QATTN_LAYOUT_K16FRAG 3
+#define QATTN_LAYOUT_V16FRAG 4
 
 /* quantiser numerics: 0 = what the reference's compiled GPU path computes (fp32 scale,
  * quotient rounded to the input dtype), 1 = the reference's eager arithmetic (everything in the input dtype). */
@@ -128,6 +134,18 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
                                 const float* scale_q, const float* scale_k, const float* scale_v, int B, int Hq,
                                 int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt, int scale_mode,
                                 int is_causal, float sm_scale, void* stream);
+
+/*
+ * 16-bit sibling path: the non-fp8 build of the same kernel (TK_ATTN_IS_FP8 undefined, tk/attention.py:212,238-240,
+ * 289-313) behind `quantum_attn::attention_forward(query, key, value, scale=None, is_causal=False)`
+ * (src/quantum_attn/ops.py:17-45).  q/out row-major [B,Hq,Sq,D] bf16 or fp16 (`fmt`); k16/v16 are the key/value
+ * tensors re-laid by qattn_pack16 into QATTN_LAYOUT_K16FRAG / QATTN_LAYOUT_V16FRAG (qattn_16bit_tensor_bytes bytes).
+ * D in {64,128}.  Both GEMMs run on v_mfma_f32_32x32x16_{bf16,f16}; softmax, running max/sum and accumulation fp32.
+ */
+size_t qattn_16bit_tensor_bytes(int layout, int B, int H, int S, int D);
+int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H, int S, int D, int out_layout, void* stream);
+int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, void* out, float* lse, int B, int Hq,
+                               int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,9 +10,9 @@ LIB_PATH = os.path.join(_HERE, "libqattn_hip.so")
 
 FMT_E4M3, FMT_E5M2, FMT_BF16, FMT_FP16 = 0, 1, 2, 3
 SCALE_HEAD, SCALE_TOKEN = 0, 1
-LAYOUT_ROWMAJOR, LAYOUT_KFRAG, LAYOUT_VFRAG = 0, 1, 2
+LAYOUT_ROWMAJOR, LAYOUT_KFRAG, LAYOUT_VFRAG, LAYOUT_K16FRAG, LAYOUT_V16FRAG = 0, 1, 2, 3, 4
 NUMERICS = {"compiled": 0, "eager": 1}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _FMT_OF_DTYPE = {
     torch.float8_e4m3fn: FMT_E4M3,
@@ -26,6 +26,7 @@ EXPORTS = (
     "qattn_abi_version", "qattn_strerror", "qattn_check_device", "qattn_fp8_tensor_bytes",
     "qattn_quant_workspace_bytes", "qattn_quant_fp8", "qattn_quant_qkv_workspace_bytes", "qattn_quant_qkv_fp8",
     "qattn_pack_fp8", "qattn_fp8_attention_forward",
+    "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16",
 )
 
 _lib = None
@@ -61,6 +62,12 @@ def lib() -> ctypes.CDLL:
     L.qattn_pack_fp8.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.qattn_fp8_attention_forward.restype = i
     L.qattn_fp8_attention_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp]
+    L.qattn_16bit_tensor_bytes.restype = sz
+    L.qattn_16bit_tensor_bytes.argtypes = [i, i, i, i, i]
+    L.qattn_pack16.restype = i
+    L.qattn_pack16.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.qattn_attention_forward_16.restype = i
+    L.qattn_attention_forward_16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
     if L.qattn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libqattn_hip.so ABI {L.qattn_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = L
@@ -172,4 +179,34 @@ def fp8_attention_forward(q8: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.
             B, Hq, Hkv, Sq, Skv, D, fmt_of(q8.dtype), fmt_of(q8.dtype), fmt_of(out_dtype), mode, int(is_causal),
             float(sm_scale), _stream(q8))
     _check(rc, "qattn_fp8_attention_forward")
+    return (out, lse) if return_lse else out
+
+
+def pack16(x: torch.Tensor, layout: int) -> torch.Tensor:
+    """row-major bf16/fp16 [B,H,S,D] -> flat uint8 buffer in K16FRAG / V16FRAG layout."""
+    assert x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
+    x = x.contiguous()
+    B, H, S, D = x.shape
+    L = lib()
+    with torch.cuda.device(x.device):
+        out = torch.empty((L.qattn_16bit_tensor_bytes(layout, B, H, S, D),), dtype=torch.uint8, device=x.device)
+        rc = L.qattn_pack16(x.data_ptr(), out.data_ptr(), B, H, S, D, layout, _stream(x))
+    _check(rc, "qattn_pack16")
+    return out
+
+
+def attention_forward_16(q: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Tensor, *, Hkv: int, Skv: int,
+                         is_causal: bool, sm_scale: float = 0.0, return_lse: bool = False):
+    """q: row-major bf16/fp16 [B,Hq,Sq,D]; k_frag / v_frag: K16FRAG / V16FRAG buffers for [B,Hkv,Skv,D]."""
+    assert q.is_cuda and q.dim() == 4
+    q = q.contiguous()
+    B, Hq, Sq, D = q.shape
+    L = lib()
+    with torch.cuda.device(q.device):
+        out = torch.empty_like(q)
+        lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if return_lse else None
+        rc = L.qattn_attention_forward_16(q.data_ptr(), k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
+                                          B, Hq, Hkv, Sq, Skv, D, fmt_of(q.dtype), int(is_causal), float(sm_scale),
+                                          _stream(q))
+    _check(rc, "qattn_attention_forward_16")
     return (out, lse) if return_lse else out

@@ -12,6 +12,7 @@ from . import config
 from .utils import checks
 
 _HIP_SUPPORTED_HEAD_DIMS = [64, 128, 256]  # nn.py:45
+_HIP_16BIT_HEAD_DIMS = [64, 128]  # the 16-bit kernel keeps O^T (D/32 x 16 fp32) + Q^T (D/4 dwords) in registers
 _FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
 
 
@@ -38,8 +39,20 @@ def _validate_hip_input(query, key, value, attn_mask=None, dropout_p=0.0, is_cau
     if scale is not None:
         return False, "NYI: scale must be None"
     if scaling_method is None:
-        return False, "NYI: the 16-bit (non-fp8) attention kernel is not built yet on gfx950"
-    if scaling_method not in ("head-wise", "token-wise"):
+        # 16-bit sibling path (nn.py:325-391 -> ops.py:17-45): q, k, v share one 16-bit dtype; D in {64,128}
+        if query.dtype not in (torch.float16, torch.bfloat16):
+            return (
+                False,
+                f"Expected query to have dtype torch.float16 or torch.bfloat16, but got query.dtype: {query.dtype} instead.",
+            )
+        if query.dtype != value.dtype:
+            return (
+                False,
+                f"Expected query and value to have the same dtype, but got query.dtype: {query.dtype}, value.dtype: {value.dtype} instead.",
+            )
+        if query.dim() == 4 and query.size(-1) not in _HIP_16BIT_HEAD_DIMS:
+            return False, f"Unsupported head dimension: {query.size(-1)}"
+    elif scaling_method not in ("head-wise", "token-wise"):
         return False, f"Unsupported scaling_method: {scaling_method}"
     if query.dtype not in (torch.float16, torch.bfloat16) + _FP8_DTYPES:
         return (
@@ -146,7 +159,9 @@ def dynamically_quantize_fp8(t: torch.Tensor, *, reduction_dim=-1) -> Tuple[torc
 
 
 def _attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None) -> Tensor:
-    raise ValueError("Unsupported input: the 16-bit (non-fp8) attention kernel is not built yet on gfx950")
+    """nn.py:310-322 -> quantum_attn::attention_forward (ops.py:17-45), here the bf16/fp16 MFMA kernel."""
+    return _ops().attention_forward(query, key, value, attn_mask=attn_mask, dropout_p=dropout_p,
+                                    is_causal=is_causal, scale=scale)
 
 
 def attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None) -> Tensor:

@@ -29,6 +29,34 @@ def _check_op_args(attn_mask, dropout_p, scale):
         raise RuntimeError("dropout_p must be 0.0 for the gfx950 attention kernel")
 
 
+@_custom_op("quantumattention_amd::attention_forward", mutates_args=(), device_types=("cuda",))
+def attention_forward(
+    query: torch.Tensor,
+    key: torch.Tensor,
+    value: torch.Tensor,
+    attn_mask: Optional[torch.Tensor] = None,
+    dropout_p: float = 0.0,
+    is_causal: bool = False,
+    *,
+    scale: Optional[float] = None,
+) -> torch.Tensor:
+    """16-bit sibling op, same schema as quantum_attn::attention_forward (ops.py:32-42): query/key/value bf16 or fp16
+    [B,H,S,D]; K and V are re-laid into MFMA fragment order, then the bf16/fp16 MFMA kernel runs."""
+    _check_op_args(attn_mask, dropout_p, scale)
+    if query.dtype not in (torch.bfloat16, torch.float16) or key.dtype != query.dtype or value.dtype != query.dtype:
+        raise RuntimeError(f"query/key/value must share bf16 or fp16, got {query.dtype}, {key.dtype}, {value.dtype}")
+    B, Hkv, Skv, D = key.shape
+    k_frag = _native.pack16(key, _native.LAYOUT_K16FRAG)
+    v_frag = _native.pack16(value, _native.LAYOUT_V16FRAG)
+    return _native.attention_forward_16(query, k_frag, v_frag, Hkv=Hkv, Skv=Skv, is_causal=is_causal,
+                                        sm_scale=0.0 if scale is None else float(scale))
+
+
+@_register_fake("quantumattention_amd::attention_forward")
+def _(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None):
+    return _out_like(query, value)
+
+
 @_custom_op("quantumattention_amd::fp8_attention_forward", mutates_args=(), device_types=("cuda",))
 def fp8_attention_forward(
     query: torch.Tensor,
