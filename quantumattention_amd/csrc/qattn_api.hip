@@ -94,8 +94,11 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
                     (void)hipMemcpy(sg.data(), p.dbg_buf + 2 * (1 << 19), sizeof(unsigned long long) * 64 * 8, hipMemcpyDeviceToHost);
                     double tot[6] = {0, 0, 0, 0, 0, 0};
                     for (int w = 0; w < 64; w++) for (int i = 0; i < 6; i++) tot[i] += (double)sg[w * 8 + i] / 64.0;
-                    fprintf(stderr, "[qattn dbg] per-iteration segment cycles (mean of 64 waves): seg0 %.0f | seg1 %.0f | seg2 %.0f | seg3 %.0f | seg4 %.0f\n",
-                            tot[0] / iters, tot[1] / iters, tot[2] / iters, tot[3] / iters, tot[4] / iters);
+                    fprintf(stderr, "[qattn dbg] per-iteration segment cycles (mean of 64 waves): seg0 %.0f | seg1 %.0f | seg2 %.0f | seg3 %.0f | seg4 %.0f | seg5 %.0f\n",
+                            tot[0] / iters, tot[1] / iters, tot[2] / iters, tot[3] / iters, tot[4] / iters, tot[5] / iters);
+                    for (int w = 0; w < 8; w++)
+                        fprintf(stderr, "[qattn dbg]   wave %d: %.0f %.0f %.0f %.0f %.0f %.0f\n", w, (double)sg[w * 8] / iters, (double)sg[w * 8 + 1] / iters,
+                                (double)sg[w * 8 + 2] / iters, (double)sg[w * 8 + 3] / iters, (double)sg[w * 8 + 4] / iters, (double)sg[w * 8 + 5] / iters);
                 }
                 fprintf(stderr, "[qattn dbg] waves=%zu sweep cycles median=%.0f (%.1f per iteration over %d) p10=%.0f p90=%.0f | in-kernel clock median %.3f GHz\n",
                         cyc.size(), cyc[cyc.size() / 2], cyc[cyc.size() / 2] / iters, iters, cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10], clk[clk.size() / 2]);

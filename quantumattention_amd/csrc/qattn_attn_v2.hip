@@ -86,6 +86,7 @@ struct WaveState {
     float m_run;   // running max of the raw scores
     float l_run;   // this lane's partial row sum of P' (exact-exp mode)
     v16f l16;      // BYTE mode: every register = the full row sum of the quantised P', accumulated by a ones-row MFMA
+    v8i ones;      // BYTE mode: the all-ones A operand of that MFMA, kept opaque so it is not re-materialised every iteration
     float c;       // scale_q*scale_k*sm_scale*log2(e)
     unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
     unsigned long long tlast;
@@ -177,11 +178,38 @@ __device__ __forceinline__ void exp_group(const v16f& sx, int j, float c, float 
 // 2^e*(1+m/8), so byte ~= 8*x + 56 (Schraudolph's exponent trick at 3 mantissa bits): one fma + one saturating
 // round-to-nearest v_cvt_pk_u8_f32 per score (profiles/r01_cvt_u8_probe.log) instead of fma + v_exp_f32 + half a
 // v_cvt_pk_fp8_f32 (~17 issue cycles -> ~6).  c8 = 8c, off8 = 8*(shift - m*c) + 56 + kByteBias.  -inf -> 0.
+template <bool PKFMA>
 __device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, float off8, v8i& pv, int w, int seed) {
+    // 5 VALU per 4 scores: two v_pk_fma_f32 (c8/off8 carry a factor 1/65535), two v_cvt_pknorm_u16_f32 (round to nearest,
+    // clamps to [0, 65535], -inf/NaN -> 0: profiles/r01_pknorm_probe.log) and one v_perm_b32 gathering the four low bytes
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    (void)seed;
+    // op_sel_hi:[1,0,0]: both halves take the LOW register of the c8 / off8 pairs, whose high halves stay unset
+    // (the compiler scalarises a <2 x float> fma with splat operands into two v_fma_f32, hence the asm)
+    const f2 cc = {c8, __builtin_nondeterministic_value(c8)}, oo = {off8, __builtin_nondeterministic_value(off8)};
+    f2 a, b2;
+    if (PKFMA) {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(a) : "v"(f2{sx[4 * j + 0], sx[4 * j + 1]}), "v"(cc), "v"(oo));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(b2) : "v"(f2{sx[4 * j + 2], sx[4 * j + 3]}), "v"(cc), "v"(oo));
+    } else {
+        a = f2{__builtin_fmaf(sx[4 * j + 0], c8, off8), __builtin_fmaf(sx[4 * j + 1], c8, off8)};
+        b2 = f2{__builtin_fmaf(sx[4 * j + 2], c8, off8), __builtin_fmaf(sx[4 * j + 3], c8, off8)};
+    }
+    const us2 qa = __builtin_amdgcn_cvt_pknorm_u16(a[0], a[1]), qb = __builtin_amdgcn_cvt_pknorm_u16(b2[0], b2[1]);
+    unsigned ua, ub;
+    __builtin_memcpy(&ua, &qa, 4);
+    __builtin_memcpy(&ub, &qb, 4);
+    unsigned b = __builtin_amdgcn_perm(ub, ua, 0x06040200u);
+    asm volatile("" : "+v"(b));  // stays in this slot
+    pv[w] = (int)b;
+}
+
+__device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, float off8, v8i& pv, int w, int seed) {
     unsigned b = (unsigned)seed;
 #pragma unroll
     for (int i = 0; i < 4; i++) b = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(sx[4 * j + i], c8, off8), i, b);
-    asm volatile("" : "+v"(b));  // stays in this slot
+    asm volatile("" : "+v"(b));
     pv[w] = (int)b;
 }
 
@@ -200,7 +228,8 @@ __device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, floa
 #define QATTN_SM_GROUP(FIRST, SX, J, MC, W, SEED)                                   \
     do {                                                                            \
         if (ABL & 4) break;                                                         \
-        if (BYTE) byte_group(SX, J, cx, MC, pc, W, SEED);                            \
+        if (BYTE && (ABL & 32)) byte_group_u8(SX, J, cx, MC, pc, W, SEED);           \
+        else if (BYTE) byte_group<(ABL & 64) != 0>(SX, J, cx, MC, pc, W, SEED);      \
         else exp_group<TWO, FIRST>(SX, J, cx, MC, acc, pc, pcl, W, SEED);            \
     } while (0)
 
@@ -231,8 +260,10 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     constexpr float SHIFT = BYTE ? kPShiftByte : kPShift, THR = BYTE ? kRescaleThrByte : kRescaleThr;
     const float c = st.c;
     // exact mode: p' = exp2(s*c + mc);  byte mode: byte = rne(s*c8 + mc)  (c8 = 8c, mc = 8*(shift - m*c) + 56 + bias)
-    const float cx = BYTE ? 8.0f * c : c;
-    const float mc = BYTE ? __builtin_fmaf(-8.0f * st.m_run, c, 8.0f * SHIFT + 56.0f + kByteBias) : SHIFT - st.m_run * c;
+    // (byte mode carries the 1/65535 of v_cvt_pknorm_u16_f32's [0,1] -> [0,65535] map in both constants)
+    constexpr float U16 = (ABL & 32) ? 1.0f : 1.0f / 65535.0f;
+    const float cx = BYTE ? (8.0f * U16) * c : c;
+    const float mc = BYTE ? __builtin_fmaf((-8.0f * U16) * st.m_run, c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - st.m_run * c;
     float acc[4];
 
     // slot 0: O0 += V0.P(t-2)            reads: V2            VALU: max over tile 0
@@ -269,12 +300,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     QATTN2_STAMP(1);
     stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
-    if (BYTE) {
-        v8i ones;
-#pragma unroll
-        for (int w = 0; w < 8; w++) ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;  // 1.0 in e4m3 / e5m2
-        st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(ones, pp, st.l16);
-    }
+    if (BYTE) st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.ones, pp, st.l16);
     v8i qg = LDSF(qbuf + (1 << 11));   // Q k-step 1
     v8i kc = LDSF(kbuf + (1 << 11));   // K(tile 0, k-step 1)
     QATTN_SM_GROUP(false, sc0, 3, mc, 3, pc[2]);
@@ -321,7 +347,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
             for (int r = 0; r < 16; r++) st.l16[r] *= alpha;
         }
         st.m_run = m_new;
-        const float mc2 = BYTE ? __builtin_fmaf(-8.0f * m_new, c, 8.0f * SHIFT + 56.0f + kByteBias) : SHIFT - m_new * c;
+        const float mc2 = BYTE ? __builtin_fmaf((-8.0f * U16) * m_new, c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - m_new * c;
         QATTN_SM_GROUP(true, sc0, 0, mc2, 0, 0);
 #pragma unroll
         for (int j = 1; j < 4; j++) QATTN_SM_GROUP(false, sc0, j, mc2, j, 0);
@@ -354,18 +380,40 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     // Between barriers a wave runs G 64-key iterations freely, so the two waves of a SIMD drift apart instead of being
     // re-aligned every chunk.  Slots live during iterations t .. t+G-1: stages t-1 (V of PV) .. t+G-1; being written:
     // t+G .. t+2G-1  ->  2G+1 distinct slots.
-    auto dma_for = [&](int t) {
-        const int kc = min(t, p.nchunks - 1), vc = min(max(t - 1, 0), p.nchunks - 1);  // stage(t) = {K(t), V(t-1)}
-        stage_dma<D, NW>(kg + (long)kc * CH, vg + (long)vc * CH, smem + (t % kStagesV2) * STAGE, wave, lane);
+    // Stages are issued strictly in order, so the DMA source/destination advance incrementally (a handful of SALU per
+    // stage instead of ~40 for the modulo / clamp / 64-bit address arithmetic of an indexed form): koff = byte offset of
+    // K(min(t, n-1)) within the head, voff = that of V(min(max(t-1, 0), n-1)) = the previous stage's koff.
+    static_assert(2 * 64 * D / (NW * 1024) == 2 || NW != 8, "one K and one V DMA per wave and stage");
+    const unsigned char* kg_w = kg + (wave << 10);
+    const unsigned char* vg_w = vg + (wave << 10);
+    const unsigned koff_max = (unsigned)(p.nchunks - 1) * CH;
+    unsigned koff = 0, voff = 0, lds_next = 0;
+    const unsigned lane16 = (unsigned)lane << 4;
+    auto dma_next = [&]() {
+        if (NW == 8) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (koff + lane16)),
+                                             (__attribute__((address_space(3))) void*)(smem + lds_next + (wave << 10)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (voff + lane16)),
+                                             (__attribute__((address_space(3))) void*)(smem + lds_next + CH + (wave << 10)), 16, 0, 0);
+        } else {
+            stage_dma<D, NW>(kg + koff, vg + voff, smem + lds_next, wave, lane);
+        }
+        voff = koff;
+        koff = min(koff + (unsigned)CH, koff_max);
+        lds_next = lds_next + STAGE == kStagesV2 * STAGE ? 0u : lds_next + STAGE;
     };
+    auto dma_for = [&](int) { dma_next(); };
 #pragma unroll
     for (int g = 0; g < kSyncEvery; g++)
         if (g < T) dma_for(g);
+    unsigned slot_cur = 0, slot_prev = 0;
     auto sync_iter = [&](int t, bool in_step = false) -> const unsigned char* {
         (void)in_step;
         if (t % kSyncEvery == 0) {
             wait_vmcnt<0>();  // this wave's pieces of stages t .. t+G-1 have landed
+            QATTN2_STAMP(4);
             if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+            QATTN2_STAMP(5);
             if (!(ABL & 1)) {
 #pragma unroll
                 for (int g = 0; g < kSyncEvery; g++)
@@ -374,13 +422,18 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         } else {
             asm volatile("s_nop 0" ::: "memory");  // keeps the iterations of a group separate scheduling regions
         }
-        return smem + (t % kStagesV2) * STAGE + frag_lane_off;
+        return smem + slot_cur + frag_lane_off;
+    };
+    auto advance = [&]() {  // slot_cur / slot_prev: LDS offsets of stage(t) / stage(t-1), advanced once per iteration
+        slot_prev = slot_cur;
+        slot_cur = slot_cur + STAGE == kStagesV2 * STAGE ? 0u : slot_cur + STAGE;
     };
     auto do_stage = [&](int) {};
     auto full = [&](auto par_tag, int t) {
         constexpr int PAR = decltype(par_tag)::value;
         const unsigned char* kbuf = sync_iter(t, true);
-        const unsigned char* vprev = smem + ((t - 1) % kStagesV2) * STAGE + CH + frag_lane_off;
+        const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
+        advance();
         QATTN2_STAMP(0);
         prep_scores<CAUSAL, TOKEN>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
@@ -390,6 +443,11 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     using P1 = std::integral_constant<int, 1>;
     for (int i = 0; i < 6; i++) st.seg[i] = 0;
     st.tlast = __builtin_amdgcn_s_memtime();
+    if (BYTE) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) st.ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;  // 1.0 in e4m3 / e5m2
+        if (ABL & 128) asm volatile("" : "+v"(st.ones));
+    }
 
     // t = 0: QK(0) only
     {
@@ -397,6 +455,7 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         qk_chunk<QK_FMT, D>(kbuf, qbuf, st.s[0][0], st.s[0][1]);
         st.vpre[0] = lds_read_frag(kbuf + CH + (0 << 11));  // stage(0)'s V part (= V(0), multiplied by P = 0 at t = 1)
         st.vpre[1] = lds_read_frag(kbuf + CH + (1 << 11));
+        advance();
     }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
@@ -411,7 +470,7 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     // t = n_w + 1: the last chunk's PV (V(t-2) lives in stage(t-1); its row blocks 0,1 are already in vpre)
     {
         (void)sync_iter(t);
-        const unsigned char* vprev = smem + ((t - 1) % kStagesV2) * STAGE + CH + frag_lane_off;
+        const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         const v8i fc = lds_read_frag(vprev + (2 << 11)), fd = lds_read_frag(vprev + (3 << 11));
         // two fully static copies: any run-time choice between st.p[0] and st.p[1] (even by value) ends up as a pointer
         // phi that keeps the P registers in scratch memory
@@ -429,12 +488,7 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
                 st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
                 st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
             }
-            if (BYTE) {
-                v8i ones;
-#pragma unroll
-                for (int w = 0; w < 8; w++) ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;
-                st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(ones, pp, st.l16);
-            }
+            if (BYTE) st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.ones, pp, st.l16);
         };
         if (t & 1) tail(P1{}); else tail(P0{});
         ++t;
@@ -602,8 +656,9 @@ static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st)
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, 0, p.nqb);                             \
             return QATTN_OK;                                                                                       \
         }
-        switch ((p.dbg & 32) ? 16 : (p.dbg & 15)) {
+        switch ((p.dbg & 15) | ((p.dbg & 32) ? 16 : 0) | ((p.dbg & 64) ? 32 : 0) | ((p.dbg & 128) ? 64 : 0)) {
             QATTN_ABL_CASE(16) QATTN_ABL_CASE(1) QATTN_ABL_CASE(2) QATTN_ABL_CASE(4) QATTN_ABL_CASE(8) QATTN_ABL_CASE(12) QATTN_ABL_CASE(15) QATTN_ABL_CASE(3) QATTN_ABL_CASE(11)
+            QATTN_ABL_CASE(18) QATTN_ABL_CASE(32) QATTN_ABL_CASE(64) QATTN_ABL_CASE(96)
             default: break;
         }
 #undef QATTN_ABL_CASE
