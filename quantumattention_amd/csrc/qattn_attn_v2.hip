@@ -86,6 +86,7 @@ struct WaveState {
     float m_run;   // running max of the raw scores
     float l_run;   // this lane's partial row sum of P' (exact-exp mode)
     v16f l16;      // BYTE mode: every register = the full row sum of the quantised P', accumulated by a ones-row MFMA
+    v8i qreg[2];   // QREG kernels: the wave's Q^T fragments (both k-steps) held in registers instead of re-read from LDS
     v8i ones;      // BYTE mode: the all-ones A operand of that MFMA, kept opaque so it is not re-materialised every iteration
     float c;       // scale_q*scale_k*sm_scale*log2(e)
     unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
@@ -287,7 +288,8 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     // slot 2: O2 += V2.P(t-2)            reads: Q k-step 0, K(tile 0, k-step 0)      VALU: group 1
     st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, pp, st.o[2]);
     if (TWO) st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
-    v8i qf = LDSF(qbuf);
+    v8i qf;
+    if (QREG) qf = st.qreg[0]; else qf = LDSF(qbuf);
     v8i ka = LDSF(kbuf + (0 << 11));
     QATTN_SM_GROUP(false, sc0, 1, mc, 1, pc[0]);
     QATTN_SLOT_FENCE();
@@ -301,7 +303,8 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
     if (BYTE) st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.ones, pp, st.l16);
-    v8i qg = LDSF(qbuf + (1 << 11));   // Q k-step 1
+    v8i qg;                            // Q k-step 1
+    if (QREG) qg = st.qreg[1]; else qg = LDSF(qbuf + (1 << 11));
     v8i kc = LDSF(kbuf + (1 << 11));   // K(tile 0, k-step 1)
     QATTN_SM_GROUP(false, sc0, 3, mc, 3, pc[2]);
     QATTN_SLOT_FENCE();
@@ -565,7 +568,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     st.c = c;
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
-    constexpr bool QREG = false;  // (Q^T in registers gained 1-3 % with register staging; with the 5-slot DMA ring the headroom is gone)
+    constexpr bool QREG = BYTE && !TWO && !(ABL & 128);  // one-term byte kernel: 16 registers to spare for the Q^T fragments
+    if (QREG) {
+        st.qreg[0] = lds_read_frag(qbuf);
+        st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
+    }
     kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt);
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();

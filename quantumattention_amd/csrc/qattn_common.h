@@ -71,4 +71,66 @@ __device__ inline int cvt4_fp8(float a, float b, float c, float d) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 8 consecutive 16-bit inputs -> 8 fp8 bytes, bit-exact to  fp8(clamp(round16(x / scale), +-qmax))  (nn.py:14-19 as the
+// reference's compiled path evaluates it: IEEE fp32 quotient, rounded to the input dtype, clamped, RNE to fp8).
+// The IEEE divide + software bf16 rounding cost ~40 VALU per element and made the pre-pass VALU-bound, so bf16
+// inputs take a fast path: q' = x * rinv with rinv = RNE(1/scale) is within 3 fp32 ulps of RNE(x/scale); both round
+// to the same bf16 unless q' lies within 4 ulps of a bf16 tie (low 16 bits near 0x8000, probability ~1.4e-4), and only
+// those vectors fall back to the exact sequence.  Requires a finite scale, which implies finite inputs (the scale is
+// derived from the group's abs-max).  Results below the fp8 subnormal range round to (signed) zero either way.
+// ---------------------------------------------------------------------------------------------------------
+template <int IN_FMT, int OUT_FMT>
+__device__ __attribute__((noinline)) int2 quant8_exact_call(const uint4 raw, float scale);
+
+template <int IN_FMT, int OUT_FMT>
+__device__ __forceinline__ int2 quant8_exact(const uint4& raw, float scale) {
+    const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
+    unsigned short e[8];
+    __builtin_memcpy(e, &raw, 16);
+    float q[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float t = round16<IN_FMT>(load16f<IN_FMT>(e[j]) / scale);  // IEEE fp32 divide, then the reference's rounding to the input dtype
+        t = t > qmax ? qmax : t;
+        t = t < -qmax ? -qmax : t;
+        q[j] = t;
+    }
+    return make_int2(cvt4_fp8<OUT_FMT>(q[0], q[1], q[2], q[3]), cvt4_fp8<OUT_FMT>(q[4], q[5], q[6], q[7]));
+}
+
+template <int IN_FMT, int OUT_FMT>
+__device__ __attribute__((noinline)) int2 quant8_exact_call(const uint4 raw, float scale) {
+    return quant8_exact<IN_FMT, OUT_FMT>(raw, scale);
+}
+
+template <int IN_FMT, int OUT_FMT>
+__device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv) {
+    if (IN_FMT != QATTN_FMT_BF16) return quant8_exact<IN_FMT, OUT_FMT>(raw, scale);
+    const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    float q[8];
+    unsigned near = 0xffffu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        q[2 * i] = __uint_as_float(w[i] << 16) * rinv;
+        q[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u) * rinv;
+        near = min(near, min((__float_as_uint(q[2 * i]) + 0x8004u) & 0xffffu, (__float_as_uint(q[2 * i + 1]) + 0x8004u) & 0xffffu));
+    }
+    const bool slow = near < 9u || !((__float_as_uint(scale) & 0x7f800000u) != 0x7f800000u);
+    if (__builtin_expect(slow, 0)) return quant8_exact_call<IN_FMT, OUT_FMT>(raw, scale);  // one out-of-line copy: rare
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const b2 h = __builtin_convertvector(f2{q[2 * i], q[2 * i + 1]}, b2);  // v_cvt_pk_bf16_f32: RNE
+        unsigned u;
+        __builtin_memcpy(&u, &h, 4);
+        c[2 * i] = __builtin_amdgcn_fmed3f(__uint_as_float(u << 16), -qmax, qmax);
+        c[2 * i + 1] = __builtin_amdgcn_fmed3f(__uint_as_float(u & 0xffff0000u), -qmax, qmax);
+    }
+    return make_int2(cvt4_fp8<OUT_FMT>(c[0], c[1], c[2], c[3]), cvt4_fp8<OUT_FMT>(c[4], c[5], c[6], c[7]));
+}
+
 }  // namespace qattn
