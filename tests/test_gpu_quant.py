@@ -101,3 +101,32 @@ def test_fused_qkv_prepass_matches_oracle_bit_exact(shape, dtype, fp8, scaling):
             assert not full[:, :, S:, :].any(), "padding rows must be zero"
             got = full[:, :, :S, :]
         np.testing.assert_array_equal(got, ref8)
+
+
+@pytest.mark.parametrize("scaling", ["head-wise", "token-wise"])
+@pytest.mark.parametrize("numerics", ["compiled", "eager"])
+def test_quant_fast_path_bit_exact_on_adversarial_bit_patterns(scaling, numerics):
+    """The bf16 fast path (x * rcp(scale), exact fallback near bf16 ties) against the oracle's IEEE-divide sequence on
+    2 M random finite bf16 BIT PATTERNS spread over 45 binades (~300 vectors take the fallback), plus rows holding
+    inf / NaN / denormals / zeros, in every scale granularity and both numerics."""
+    rng = np.random.default_rng(7)
+    B, H, S, D = 2, 8, 1024, 128
+    n = B * H * S * D
+    bits = ((rng.integers(0, 2, n) << 15) | (rng.integers(90, 135, n) << 7) | rng.integers(0, 128, n)).astype(np.uint16)
+    bits = bits.reshape(B, H, S, D)
+    bits[0, 0, 3, :16] = 0x0001                      # bf16 denormals
+    bits[0, 0, 4, :] = 0                             # all-zero row (eps clamp in token mode)
+    bits[0, 1, 7, 5] = 0x7f80                        # +inf  -> head 1 (and that row) get an inf scale
+    bits[0, 2, 9, 11] = 0x7fc1                       # NaN   -> head 2 (and that row) get a NaN scale
+    bits[1, 3, :, :] = (bits[1, 3, :, :] & 0x807f) | (120 << 7)   # one binade only: many quotients near ties
+    m = "head" if scaling == "head-wise" else "token"
+    ref8, refs = oracle.quantize_fp8(bits, oracle.FMT_BF16, m, oracle.FMT_E4M3, numerics)
+    x = from_bits16(bits, torch.bfloat16).cuda()
+    x8, s = _native.quant_fp8(x, scaling=scaling, numerics=numerics)
+    s = s.cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(s), np.isnan(refs))                   # NaN scales in the same places (payload is free)
+    np.testing.assert_array_equal(s[~np.isnan(s)].view(np.uint32), refs[~np.isnan(refs)].view(np.uint32))
+    got = bits8(x8)
+    nan_ref = (ref8 & 0x7f) == 0x7f
+    np.testing.assert_array_equal((got & 0x7f) == 0x7f, nan_ref)     # NaN bytes in the same places (sign of NaN is free)
+    np.testing.assert_array_equal(got[~nan_ref], ref8[~nan_ref])
