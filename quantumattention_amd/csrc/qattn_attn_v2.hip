@@ -85,7 +85,11 @@ struct WaveState {
     v8i vpre[2];            // V fragments (row blocks 0,1) of the NEXT iteration's PV, read one iteration ahead
     float m_run;   // running max of the raw scores
     float l_run;   // this lane's partial row sum of P' (exact-exp mode)
-    v16f l16;      // BYTE mode: every register = the full row sum of the quantised P', accumulated by a ones-row MFMA
+    // BYTE mode: row sums of the quantised P', accumulated by ONE v_mfma_f32_16x16x128_f8f6f4 per chunk (32 cycles): its A
+    // operand is 1.0 in row 0 for k-groups 0,2 and in row 1 for k-groups 1,3, so that with the P^T fragment as B (lane =
+    // query + 32*half, 32 keys per lane) D[0][n] = sum over the 64 keys of query n and D[1][n] = that of query n + 16.
+    // lsum[0] / lsum[1] of lanes 0..15 hold them; everything else in lsum stays 0.
+    v4f lsum;
     v8i qreg[2];   // QREG kernels: the wave's Q^T fragments (both k-steps) held in registers instead of re-read from LDS
     v8i ones;      // BYTE mode: the all-ones A operand of that MFMA, kept opaque so it is not re-materialised every iteration
     float c;       // scale_q*scale_k*sm_scale*log2(e)
@@ -302,7 +306,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     QATTN2_STAMP(1);
     stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
-    if (BYTE) st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.ones, pp, st.l16);
+    if (BYTE) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
     v8i qg;                            // Q k-step 1
     if (QREG) qg = st.qreg[1]; else qg = LDSF(qbuf + (1 << 11));
     v8i kc = LDSF(kbuf + (1 << 11));   // K(tile 0, k-step 1)
@@ -346,8 +350,9 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
             for (int r = 0; r < 16; r++) st.o[m][r] *= alpha;
         st.l_run *= alpha;
         if (BYTE) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) st.l16[r] *= alpha;
+            // lane n < 16 holds the sums of queries n (its own alpha) and n + 16 (lane n+16's alpha)
+            st.lsum[0] *= alpha;
+            st.lsum[1] *= __shfl(alpha, (threadIdx.x & 15) + 16);
         }
         st.m_run = m_new;
         const float mc2 = BYTE ? __builtin_fmaf((-8.0f * U16) * m_new, c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - m_new * c;
@@ -447,9 +452,12 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     for (int i = 0; i < 6; i++) st.seg[i] = 0;
     st.tlast = __builtin_amdgcn_s_memtime();
     if (BYTE) {
+        {   // A of the row-sum MFMA: lane = row (l & 15) + 16 * k-group; rows 0 / 1 are 1.0 (e4m3 0x38) on even / odd k-groups
+            const int row = lane & 15, kg = lane >> 4;
+            const int one = ((row == 0 && !(kg & 1)) || (row == 1 && (kg & 1))) ? 0x38383838 : 0;
 #pragma unroll
-        for (int w = 0; w < 8; w++) st.ones[w] = V_FMT == QATTN_FMT_E4M3 ? 0x38383838 : 0x3c3c3c3c;  // 1.0 in e4m3 / e5m2
-        if (ABL & 128) asm volatile("" : "+v"(st.ones));
+            for (int w = 0; w < 8; w++) st.ones[w] = one;
+        }
     }
 
     // t = 0: QK(0) only
@@ -491,7 +499,7 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
                 st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
                 st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
             }
-            if (BYTE) st.l16 = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.ones, pp, st.l16);
+            if (BYTE) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
         };
         if (t & 1) tail(P1{}); else tail(P0{});
         ++t;
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
 
     WaveState<D, TWO, BYTE> st;
 #pragma unroll
-    for (int r = 0; r < 16; r++) st.l16[r] = 0.0f;
+    for (int r = 0; r < 4; r++) st.lsum[r] = 0.0f;
 #pragma unroll
     for (int m = 0; m < MB; m++)
 #pragma unroll
@@ -592,7 +600,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     // ---- epilogue: combine the two half-wave partial sums, normalise, convert, store
     float l_tot;
     if (BYTE) {
-        l_tot = st.l16[0];  // the ones-row MFMA already summed over both half-waves' keys
+        // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
+        const float s0 = __shfl(st.lsum[0], threadIdx.x & 15), s1 = __shfl(st.lsum[1], threadIdx.x & 15);
+        l_tot = (threadIdx.x & 16) ? s1 : s0;
     } else {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);

@@ -10,6 +10,7 @@ namespace qattn {
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned short v8u16 __attribute__((ext_vector_type(8)));
 
