@@ -234,7 +234,7 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
     do {                                                                            \
         if (ABL & 4) break;                                                         \
         if (BYTE && (ABL & 32)) byte_group_u8(SX, J, cx, MC, pc, W, SEED);           \
-        else if (BYTE) byte_group<(ABL & 64) != 0>(SX, J, cx, MC, pc, W, SEED);      \
+        else if (BYTE) byte_group<false>(SX, J, cx, MC, pc, W, SEED);                \
         else exp_group<TWO, FIRST>(SX, J, cx, MC, acc, pc, pcl, W, SEED);            \
     } while (0)
 
@@ -689,7 +689,8 @@ static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st)
         else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, false>(p, n_two, p.nqb - n_two, st);
         if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, true, false>(p, 0, n_two, st);
     } else {
-        if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, true>(p, n_two, p.nqb - n_two, st);
+        if (byte_exp && p.use_v4 && D == 128) rc = launch_attn_v4(p, FMT, CAUSAL, scale_mode, n_two * NW * kQPerWave, st);
+        else if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, true>(p, n_two, p.nqb - n_two, st);
         else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, false>(p, n_two, p.nqb - n_two, st);
         if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true, false>(p, 0, n_two, st);
     }

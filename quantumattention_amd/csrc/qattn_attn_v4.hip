@@ -1,0 +1,259 @@
+// qattn_attn_v4.hip -- FP8 fused attention forward, "three waves per SIMD" structure (D = 128, byte-exponential path).
+//
+// Same math, operand layouts and C-ABI entry as qattn_attn_v2.hip (replaces fwd_attend_ker, tk/attention.py:97-349), but a
+// different way of keeping the matrix pipe busy.  v2 software-pipelines QK^T / softmax / PV inside each wave and needs
+// ~222 registers, so a SIMD holds two waves whose non-MFMA phases (checks, staging, LDS waits) are aligned by the
+// workgroup barrier and leave the pipe idle ~30 % of the time.  Here every wave runs the plain sequence
+//     QK^T(t) -> max / rescale -> exponentials -> PV(t)
+// with single-buffered S and P (<= 168 registers), a workgroup is 4 waves x 32 rows with a two-stage K/V ring
+// (48 KiB LDS), and a CU holds THREE independent workgroups: each SIMD interleaves three waves that belong to different
+// workgroups, hence are never phase-aligned, and one wave's softmax hides under the other two's MFMAs.
+// Used for the one-term byte-exponential case (no LSE output); two-term blocks and exact exponentials stay on v2.
+#include "qattn_attn.h"
+
+namespace qattn {
+
+constexpr int kWaves4 = 4;
+constexpr int kQPerWG4 = kWaves4 * kQPerWave;  // 128 query rows per workgroup
+constexpr int kStages4 = 2;
+
+// 4 scores -> 4 e4m3 bytes of 2^x (see byte_group in qattn_attn_v2.hip: fma x4, v_cvt_pknorm_u16_f32 x2, v_perm_b32)
+__device__ __forceinline__ int byte_exp4(float s0, float s1, float s2, float s3, float c8, float off8) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 qa = __builtin_amdgcn_cvt_pknorm_u16(__builtin_fmaf(s0, c8, off8), __builtin_fmaf(s1, c8, off8));
+    const us2 qb = __builtin_amdgcn_cvt_pknorm_u16(__builtin_fmaf(s2, c8, off8), __builtin_fmaf(s3, c8, off8));
+    unsigned ua, ub;
+    __builtin_memcpy(&ua, &qa, 4);
+    __builtin_memcpy(&ub, &qb, 4);
+    return (int)__builtin_amdgcn_perm(ub, ua, 0x06040200u);
+}
+
+template <int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
+__global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n) {
+    constexpr int D = 128, CH = 64 * D, STAGE = 2 * CH, MB = D / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+
+    int head, qb;
+    map_block(p, blockIdx.x, qb_n, CAUSAL, head, qb);
+    qb += qb_lo;
+    const int b = head / p.Hq, h = head % p.Hq;
+    const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+    const int q0_wg = qb * kQPerWG4, q0 = q0_wg + wave * kQPerWave, qrow = q0 + ql;
+    const unsigned char* kg_w = p.k + kv_head * (long)p.nchunks * CH + (wave << 10);
+    const unsigned char* vg_w = p.v + kv_head * (long)p.nchunks * CH + (wave << 10);
+    const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + kQPerWG4, p.Sq) - 1) / 64 + 1) : p.nchunks;
+    const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
+
+    // stage(t) = {K chunk t, V chunk t} -> slot t & 1; every wave copies 4 x 1 KiB of it by LDS-DMA
+    const unsigned lane16 = (unsigned)lane << 4;
+    unsigned coff = 0, slot_next = 0;
+    auto dma_next = [&]() {
+        unsigned char* dst = smem + slot_next + (wave << 10);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (coff + lane16 + r * 4096)),
+                                             (__attribute__((address_space(3))) void*)(dst + r * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (coff + lane16 + r * 4096)),
+                                             (__attribute__((address_space(3))) void*)(dst + CH + r * 4096), 16, 0, 0);
+        }
+        coff += CH;
+        slot_next ^= STAGE;
+    };
+    dma_next();
+
+    // Q^T fragments parked in this lane's own LDS slots (registers are the scarce resource at three waves per SIMD)
+    unsigned char* qbuf = smem + kStages4 * STAGE + wave * 4096 + (hh << 10) + (ql << 4);
+    {
+        const bool qvalid = qrow < p.Sq;
+        const unsigned char* qp = p.q + (((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            v4i lo = *reinterpret_cast<const v4i*>(qp + s * 64);
+            v4i hi = *reinterpret_cast<const v4i*>(qp + s * 64 + 16);
+            if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
+            *reinterpret_cast<v4i*>(qbuf + (s << 11)) = lo;
+            *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = hi;
+        }
+    }
+    float c;
+    if (TOKEN) c = p.sm_log2e * (qrow < p.Sq ? p.sq[((long)b * p.Hq + h) * p.Sq + qrow] : 1.0f);
+    else c = p.sm_log2e * p.sq[(long)b * p.Hq + h] * p.sk[kv_head];
+    const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
+
+    v16f o[MB];
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
+    v4f lsum = {0.0f, 0.0f, 0.0f, 0.0f};
+    v8i ones;  // A of the row-sum MFMA (see WaveState::lsum in qattn_attn_v2.hip)
+    {
+        const int row = lane & 15, kg = lane >> 4;
+        const int one = ((row == 0 && !(kg & 1)) || (row == 1 && (kg & 1))) ? 0x38383838 : 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) ones[w] = one;
+    }
+    float m_run = -1.0e30f;
+    constexpr float U16 = 1.0f / 65535.0f;
+    const float c8 = (8.0f * U16) * c;
+    const int frag_lane_off = (hh << 10) + (ql << 4);
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    for (int t = 0; t < n_wg; t++) {
+        // Q^T fragments do not depend on the stage: request them before the barrier so their LDS latency hides behind it
+        const v8i qf = lds_read_frag(qbuf), qg = lds_read_frag(qbuf + (1 << 11));
+        wait_vmcnt<0>();                  // this wave's pieces of stage t have landed
+        __builtin_amdgcn_s_barrier();     // ... and everyone's; every wave is also done with stage t-1's slot
+        if (t + 1 < n_wg) dma_next();
+        if (t >= n_w) continue;           // causal: this wave's rows end before chunk t (it keeps the barrier / DMA cadence)
+        const unsigned char* kbuf = smem + (t & 1) * STAGE + frag_lane_off;
+        const unsigned char* vbuf = kbuf + CH;
+        // ---- S^T = K.Q^T
+        const v8i ka = lds_read_frag(kbuf), kb = lds_read_frag(kbuf + (2 << 11));
+        const v8i kc = lds_read_frag(kbuf + (1 << 11)), kd = lds_read_frag(kbuf + (3 << 11));
+        v16f s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
+        s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf, s0);
+        s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf, s1);
+        s0 = mfma_f8<QK_FMT, QK_FMT>(kc, qg, s0);
+        s1 = mfma_f8<QK_FMT, QK_FMT>(kd, qg, s1);
+        // the first two V fragments travel while the softmax runs (all four would not fit in 168 registers)
+        const v8i vf0 = lds_read_frag(vbuf), vf1 = lds_read_frag(vbuf + (1 << 11));
+        // ---- token-wise key scales, ragged-tail / causal mask (rare or cheap)
+        const int k0 = t * 64;
+        if (TOKEN) {
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int kk = k0 + 32 * tt + 8 * j + 4 * hh;
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kk + 3 < p.Skv) w = *reinterpret_cast<const float4*>(skt + kk);
+                    else { if (kk < p.Skv) w.x = skt[kk]; if (kk + 1 < p.Skv) w.y = skt[kk + 1]; if (kk + 2 < p.Skv) w.z = skt[kk + 2]; }
+                    v16f& sx = tt ? s1 : s0;
+                    sx[4 * j + 0] *= w.x; sx[4 * j + 1] *= w.y; sx[4 * j + 2] *= w.z; sx[4 * j + 3] *= w.w;
+                }
+        }
+        const bool need_mask = (k0 + 64 > p.Skv) || (CAUSAL && k0 + 63 > q0);
+        if (__builtin_expect(need_mask, 0)) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const int key = k0 + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * hh;
+                const bool dead = key >= p.Skv || (CAUSAL && key > qrow);
+                v16f& sx = (r >> 4) ? s1 : s0;
+                sx[r & 15] = dead ? -INFINITY : sx[r & 15];
+            }
+        }
+        // ---- running max; rescale only when a row's max grew past the headroom of the shifted exponent
+        float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
+        mx = fmaxf(mx, s0[15]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (__builtin_expect(__any((mx - m_run) * c > kRescaleThrByte) != 0, 0)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[m][r] *= alpha;
+            lsum[0] *= alpha;
+            lsum[1] *= __shfl(alpha, (lane & 15) + 16);
+            m_run = m_new;
+        }
+        // ---- P = e4m3 bytes of 2^(c*(s - m) + shift)
+        const float off8 = __builtin_fmaf((-8.0f * U16) * m_run, c, (8.0f * kPShiftByte + 56.0f + kByteBias) * U16);
+        v8i pv;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            pv[j] = byte_exp4(s0[4 * j], s0[4 * j + 1], s0[4 * j + 2], s0[4 * j + 3], c8, off8);
+            pv[4 + j] = byte_exp4(s1[4 * j], s1[4 * j + 1], s1[4 * j + 2], s1[4 * j + 3], c8, off8);
+        }
+        // ---- O^T += V^T.P^T, row sums
+        const v8i vf2 = lds_read_frag(vbuf + (2 << 11)), vf3 = lds_read_frag(vbuf + (3 << 11));  // land under the first two MFMAs
+        o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf0, pv, o[0]);
+        o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf1, pv, o[1]);
+        o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf2, pv, o[2]);
+        o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf3, pv, o[3]);
+        lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+    }
+    if (p.dbg & 16) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            const long wid = (long)blockIdx.x * kWaves4 + wave;
+            p.dbg_buf[2 * wid] = t1 - dbg_t0;
+            p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
+        }
+    }
+
+    // ---- epilogue
+    const float s0l = __shfl(lsum[0], lane & 15), s1l = __shfl(lsum[1], lane & 15);
+    const float l_tot = (lane & 16) ? s1l : s0l;
+    const float sv = p.sv ? p.sv[kv_head] : 1.0f;
+    const float inv = sv / l_tot;
+    if (qrow < p.Sq) {
+        const long row_off = (((long)b * p.Hq + h) * p.Sq + qrow) * D;
+        if (p.out_fmt == QATTN_FMT_BF16) {
+            __bf16* op = reinterpret_cast<__bf16*>(p.out) + row_off;
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                    bf4 tv;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) tv[i] = (__bf16)(o[m][4 * j + i] * inv);
+                    *reinterpret_cast<bf4*>(op + 32 * m + 8 * j + 4 * hh) = tv;
+                }
+        } else {
+            _Float16* op = reinterpret_cast<_Float16*>(p.out) + row_off;
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 tv;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) tv[i] = (_Float16)(o[m][4 * j + i] * inv);
+                    *reinterpret_cast<h4*>(op + 32 * m + 8 * j + 4 * hh) = tv;
+                }
+        }
+    }
+}
+
+template <int FMT, bool CAUSAL, bool TOKEN>
+static int launch_v4_one(const AttnParams& p, int qb_lo, int qb_n, hipStream_t st) {
+    if (qb_n <= 0) return QATTN_OK;
+    const int grid = p.B * p.Hq * qb_n;
+    const size_t lds = (size_t)kStages4 * 2 * 64 * 128 + (size_t)kWaves4 * 4096;  // K/V ring + parked Q^T fragments = 48 KiB
+    auto kern = attn_fwd_kernel_v4<FMT, FMT, CAUSAL, TOKEN>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves4 * 64), lds, st, p, qb_lo, qb_n);
+    return QATTN_OK;
+}
+
+// Rows [row_lo, Sq) of every head on the v4 kernel (row_lo a multiple of 128).  D = 128, byte-exponential, no LSE.
+int launch_attn_v4(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
+    const int qb_lo = row_lo / kQPerWG4, qb_n = ceil_div(p.Sq, kQPerWG4) - qb_lo;
+    const bool tok = scale_mode == QATTN_SCALE_TOKEN;
+#define QATTN_V4(F, C, T) return launch_v4_one<F, C, T>(p, qb_lo, qb_n, st)
+    if (fmt == QATTN_FMT_E4M3) {
+        if (causal) { if (tok) QATTN_V4(QATTN_FMT_E4M3, true, true); else QATTN_V4(QATTN_FMT_E4M3, true, false); }
+        else { if (tok) QATTN_V4(QATTN_FMT_E4M3, false, true); else QATTN_V4(QATTN_FMT_E4M3, false, false); }
+    } else {
+        if (causal) { if (tok) QATTN_V4(QATTN_FMT_E5M2, true, true); else QATTN_V4(QATTN_FMT_E5M2, true, false); }
+        else { if (tok) QATTN_V4(QATTN_FMT_E5M2, false, true); else QATTN_V4(QATTN_FMT_E5M2, false, false); }
+    }
+#undef QATTN_V4
+}
+
+}  // namespace qattn

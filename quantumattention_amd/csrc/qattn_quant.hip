@@ -69,7 +69,10 @@ __device__ __forceinline__ void vfrag_copy_out(const unsigned char* img, unsigne
     for (int k = 0; k < (2 * D + 255) / 256; k++) {
         const int blk = k * 256 + tid;
         if (2 * D < 256 && blk >= 2 * D) break;
-        const int wh = blk & 1, dq = (blk >> 1) & 7, half = (blk >> 4) & 1, hh = (blk >> 5) & 1, m = blk >> 6;
+        // lane bits chosen so that the 32 lanes of a ds_read_b32 group hit 32 different banks of the 33-dword-stride image:
+        // bank = (33*row + 8m + dq) mod 32 = dq + 4hh + 16wh + 8(m&1) + const over (dq&3, hh, wh, m&1)
+        const int wh = blk & 1, hh = (blk >> 3) & 1, half = (blk >> 6) & 1;
+        const int dq = ((blk >> 1) & 3) + 4 * ((blk >> 5) & 1), m = ((blk >> 4) & 1) + 2 * (blk >> 7);
         const int d0 = 32 * m + 4 * dq;
         unsigned o[2][4];
 #pragma unroll

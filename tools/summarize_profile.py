@@ -1,0 +1,55 @@
+"""Turn the raw output of tools/profile_bench.sh (gpurun_out/prof_<tag>/) into the committed summaries:
+  profiles/<name>/kernel_stats.csv   rocprofv3 --kernel-trace --stats (qattn kernels only)
+  profiles/<name>/pmc_summary.json   mean counter value per dispatch and kernel, all PMC passes
+  profiles/traffic.json              HBM bytes per attention launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+usage: python tools/summarize_profile.py gpurun_out/prof_r01c profiles/r01_final
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+csv.field_size_limit(1 << 30)
+
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    with open(stats[0]) as f, open(os.path.join(dst, "kernel_stats.csv"), "w") as g:
+        for i, line in enumerate(f):
+            if i == 0 or "qattn::" in line:
+                g.write(line)
+
+summary = {}
+for cc in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    acc = {}
+    with open(cc) as f:
+        for row in csv.DictReader(f):
+            name = row["Kernel_Name"]
+            if "qattn::" not in name:
+                continue
+            key = name.split("(")[0][:90]
+            acc.setdefault((key, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+    for (k, c), v in acc.items():
+        summary.setdefault(k, {})[c] = sum(v) / len(v)
+with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+
+attn = [k for k in summary if "attn_fwd_kernel" in k]
+if attn:
+    s = summary[attn[0]]
+    # FETCH_SIZE / WRITE_SIZE count 64-byte... units of 1 KiB per the guide's rocprofv3 section; FETCH_SIZE under-reports by 2x on gfx950
+    fetch = s["FETCH_SIZE"] * 1024 * 2
+    write = s["WRITE_SIZE"] * 1024
+    B, H, S, D = 4, 32, 4096, 128
+    out = {
+        "attn_fwd_hbm_bytes_per_launch": fetch + write,
+        "fetch_bytes_x2_corrected": fetch,
+        "write_bytes": write,
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; %s/pmc_summary.json" % dst,
+        "algorithmic_bytes": B * H * S * D * (3 + 2),
+    }
+    with open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
