@@ -140,6 +140,15 @@ def main():
 
     attn_ms = event_time(attn_only, args.steps)
     quant_ms = event_time(quant_only, args.steps)
+    # informational: the same step replayed from a HIP graph (no launch gaps); `value` stays the eager API call
+    graph_ms = None
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        graph_ms = event_time(g.replay, args.steps)
+    except Exception as exc:  # capture is optional evidence, never fatal for the benchmark line
+        print(f"[bench] HIP graph capture skipped: {exc}", file=sys.stderr)
 
     if rank == 0:
         f_gpu = flops(B, H, S, S, D, args.causal)
@@ -159,7 +168,7 @@ def main():
                                    f"{'; batch-sharded B=%d total' % (B * world) if world > 1 else ''})",
                        "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collectives"},
             "frac_of_fp8_mfma_peak": value / (FP8_PEAK_TFLOPS * world),
-            "attn_kernel_ms": attn_ms, "quant_prepass_ms": quant_ms,
+            "attn_kernel_ms": attn_ms, "quant_prepass_ms": quant_ms, "graph_replay_ms_per_step": graph_ms,
             "roofline": {"kernel": "qattn::attn_fwd_kernel_v2<128,8,e4m3,e4m3,...> (fused QK^T/softmax/PV)", "bound": "mfma", "achieved": achieved,
                          "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP8_PEAK_TFLOPS,
                          "traffic": traffic},

@@ -193,3 +193,30 @@ def test_full_size_properties_B4_H32_S4096_D128(causal):
         outp = qa.fp8_attn_func(q[:1], k[:1, :, perm], v[:1, :, perm])
         # both runs round P to fp8 in different chunk groupings: each is within TOL/2 of the oracle here
         assert (outp.float() - out[:1].float()).abs().max() < TOL
+
+
+def test_hip_graph_capture_of_the_whole_step():
+    """The C ABI promises "no host synchronisation, no allocation, graph-capture safe" (include/qattn.h): capture
+    quant pre-pass + attention (and the 16-bit path) in a HIP graph, replay it on new input data, compare bit-exactly
+    with the eager launches."""
+    torch.manual_seed(11)
+    B, H, S, D = 2, 8, 1024, 128
+    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):  # warm-up outside the capture (lazy module load, hipFuncSetAttribute)
+            qa.fp8_attn_func(q, k, v, is_causal=True)
+            qa.attn_func(q, k, v)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out8 = qa.fp8_attn_func(q, k, v, is_causal=True)
+        out16 = qa.attn_func(q, k, v)
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        q.copy_(torch.randn_like(q)); k.copy_(torch.randn_like(k)); v.copy_(torch.randn_like(v))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out8, qa.fp8_attn_func(q, k, v, is_causal=True))
+        assert torch.equal(out16, qa.attn_func(q, k, v))
