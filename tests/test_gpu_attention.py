@@ -220,3 +220,19 @@ def test_hip_graph_capture_of_the_whole_step():
         torch.cuda.synchronize()
         assert torch.equal(out8, qa.fp8_attn_func(q, k, v, is_causal=True))
         assert torch.equal(out16, qa.attn_func(q, k, v))
+
+
+@pytest.mark.parametrize("backend", ["eager", "aot_eager"])
+def test_torch_compile_traces_the_ops_as_opaque_calls(backend):
+    """inside a user's torch.compile region the custom ops are traced through their fake impls
+    (register_fake) and run the same HIP kernels -- results bit-equal to the eager call, for the fp8 and the 16-bit path,
+    with dynamic sequence length (head count / head_dim marked static as nn.py:484-488 does)."""
+    torch.manual_seed(5)
+
+    def f(q, k, v):
+        return qa.fp8_attn_func(q * 1.0, k, v, is_causal=True) + qa.attn_func(q, k, v).to(q.dtype) * 0
+
+    cf = torch.compile(f, backend=backend, dynamic=True)
+    for S in (256, 384):
+        q, k, v = (torch.randn(1, 4, S, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+        assert torch.equal(cf(q, k, v), f(q, k, v))
