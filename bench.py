@@ -173,7 +173,7 @@ def main():
                          "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP8_PEAK_TFLOPS,
                          "traffic": traffic},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, q, k, v)
         print(json.dumps(line), flush=True)
     if dist is not None:

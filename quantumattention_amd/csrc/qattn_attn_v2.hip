@@ -24,6 +24,8 @@
 //  * P is scaled by 2^kPShift before the e4m3 conversion; where few keys are visible P is split hi+lo (two terms).
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "qattn_attn.h"
 
 namespace qattn {
@@ -660,8 +662,9 @@ static int launch_attn_v2_one(const AttnParams& p, int qb_lo, int qb_n, hipStrea
 template <int D, int NW, int FMT, bool CAUSAL>
 static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st) {
     int n_two;  // leading q-blocks that need two-term P
-    if (CAUSAL) n_two = min(p.nqb, ceil_div(min(kTwoTermKeys, p.Skv), NW * kQPerWave));
-    else n_two = p.Skv < kTwoTermKeys ? p.nqb : 0;
+    static const int two_keys = getenv("QATTN_TWO_TERM_KEYS") ? atoi(getenv("QATTN_TWO_TERM_KEYS")) : kTwoTermKeys;  // development switch
+    if (CAUSAL) n_two = min(p.nqb, ceil_div(min(two_keys, p.Skv), NW * kQPerWave));
+    else n_two = p.Skv < two_keys ? p.nqb : 0;
     if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
         const int grid = p.B * p.Hq * p.nqb;
