@@ -72,7 +72,8 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
     p.sm_log2e = sm * 1.4426950408889634f;
     p.exact_exp = exact_exp();
-    p.use_v4 = kernel_variant() == 4 ? 1 : 0;
+    p.use_v4 = (kernel_variant() == 4 || (D != 128 && kernel_variant() == 2)) ? 1 : 0;  // D = 64 / 256: v4 by default
+    p.v1_qb_n = 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (use_v1) rc = launch_attn_v1(p, D, qk_fmt, is_causal, scale_mode, st);

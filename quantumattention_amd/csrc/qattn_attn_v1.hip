@@ -63,15 +63,16 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v1(const AttnPara
     int bid = blockIdx.x;
     int head, qb;
     const int NH = p.B * p.Hq;
+    const int nqb_l = p.v1_qb_n > 0 ? p.v1_qb_n : p.nqb;  // this launch covers query blocks [0, nqb_l)
     if (p.xcd_remap) {
         const int xcd = bid & 7, idx = bid >> 3;
-        head = xcd * (NH >> 3) + idx / p.nqb;
-        qb = idx % p.nqb;
+        head = xcd * (NH >> 3) + idx / nqb_l;
+        qb = idx % nqb_l;
     } else {
-        head = bid / p.nqb;
-        qb = bid % p.nqb;
+        head = bid / nqb_l;
+        qb = bid % nqb_l;
     }
-    if (CAUSAL) qb = p.nqb - 1 - qb;  // heaviest query blocks first
+    if (CAUSAL) qb = nqb_l - 1 - qb;  // heaviest query blocks first
     const int b = head / p.Hq, h = head % p.Hq;
     const int hkv = h / (p.Hq / p.Hkv);
     const long kv_head = (long)b * p.Hkv + hkv;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel_v1(const AttnPara
 
 template <int D, int FMT, bool CAUSAL>
 static int launch_attn_v1_t(const AttnParams& p, int scale_mode, hipStream_t st) {
-    const int grid = p.B * p.Hq * p.nqb;
+    const int grid = p.B * p.Hq * (p.v1_qb_n > 0 ? p.v1_qb_n : p.nqb);
     const size_t lds = (size_t)kStages * 2 * 64 * D;
     if (scale_mode == QATTN_SCALE_TOKEN) {
         auto kern = attn_fwd_kernel_v1<D, FMT, FMT, CAUSAL, true>;
@@ -308,7 +309,21 @@ static int launch_attn_v1_d(const AttnParams& p, int fmt, int causal, int scale_
 
 
 
-int launch_attn_v1(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
+int launch_attn_v1(const AttnParams& pin, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
+    AttnParams p = pin;
+    p.v1_qb_n = 0;
+    // D = 64 / 256: q-blocks whose rows all see >= kTwoTermKeys keys take the byte-exponential v4 kernel (head-wise
+    // scales, no LSE, exact exponentials not requested); v1 keeps the two-term blocks and every other case.
+    if (p.use_v4 && D != 128 && scale_mode == QATTN_SCALE_HEAD && !p.exact_exp && p.lse == nullptr) {
+        int n_two;
+        if (causal) n_two = min(p.nqb, ceil_div(min(kTwoTermKeys, p.Skv), kQPerWG));
+        else n_two = p.Skv < kTwoTermKeys ? p.nqb : 0;
+        if (n_two < p.nqb) {
+            const int rc4 = launch_attn_v4(p, D, fmt, causal, scale_mode, n_two * kQPerWG, st);
+            if (rc4 != QATTN_OK || n_two == 0) return rc4;
+            p.v1_qb_n = n_two;
+        }
+    }
     if (D == 64) return launch_attn_v1_d<64>(p, fmt, causal, scale_mode, st);
     if (D == 128) return launch_attn_v1_d<128>(p, fmt, causal, scale_mode, st);
     return launch_attn_v1_d<256>(p, fmt, causal, scale_mode, st);

@@ -692,7 +692,7 @@ static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st)
         else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, false>(p, n_two, p.nqb - n_two, st);
         if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, true, false>(p, 0, n_two, st);
     } else {
-        if (byte_exp && p.use_v4 && D == 128) rc = launch_attn_v4(p, FMT, CAUSAL, scale_mode, n_two * NW * kQPerWave, st);
+        if (byte_exp && p.use_v4 && D == 128) rc = launch_attn_v4(p, 128, FMT, CAUSAL, scale_mode, n_two * NW * kQPerWave, st);
         else if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, true>(p, n_two, p.nqb - n_two, st);
         else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, false>(p, n_two, p.nqb - n_two, st);
         if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true, false>(p, 0, n_two, st);

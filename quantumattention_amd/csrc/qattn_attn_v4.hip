@@ -13,9 +13,10 @@
 
 namespace qattn {
 
-constexpr int kWaves4 = 4;
-constexpr int kQPerWG4 = kWaves4 * kQPerWave;  // 128 query rows per workgroup
 constexpr int kStages4 = 2;
+// waves per workgroup: 4 (128 query rows; three workgroups per CU) for D <= 128, 8 for D = 256 (one workgroup per CU:
+// 64 + 64 KiB of LDS, O^T alone is 128 registers, so two waves per SIMD)
+template <int D> struct V4Shape { static constexpr int NW = D == 256 ? 8 : 4; static constexpr int WPS = D == 256 ? 2 : (D == 64 ? 4 : 3); };
 
 // 4 scores -> 4 e4m3 bytes of 2^x (see byte_group in qattn_attn_v2.hip: fma x4, v_cvt_pknorm_u16_f32 x2, v_perm_b32)
 __device__ __forceinline__ int byte_exp4(float s0, float s1, float s2, float s3, float c8, float off8) {
@@ -28,9 +29,11 @@ __device__ __forceinline__ int byte_exp4(float s0, float s1, float s2, float s3,
     return (int)__builtin_amdgcn_perm(ub, ua, 0x06040200u);
 }
 
-template <int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
-__global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n) {
-    constexpr int D = 128, CH = 64 * D, STAGE = 2 * CH, MB = D / 32;
+template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
+__global__ __launch_bounds__(V4Shape<D>::NW * 64, V4Shape<D>::WPS) void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n) {
+    constexpr int NW = V4Shape<D>::NW, kQPerWG4 = NW * kQPerWave;
+    constexpr int CH = 64 * D, STAGE = 2 * CH, MB = D / 32, KS = D / 64;
+    constexpr int RK = CH / (NW * 1024);   // 1 KiB DMA pieces per wave for the K (and for the V) part of a stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,17 +50,17 @@ __global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const Attn
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + kQPerWG4, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
 
-    // stage(t) = {K chunk t, V chunk t} -> slot t & 1; every wave copies 4 x 1 KiB of it by LDS-DMA
+    // stage(t) = {K chunk t, V chunk t} -> slot t & 1; every wave copies 2*RK x 1 KiB of it by LDS-DMA
     const unsigned lane16 = (unsigned)lane << 4;
     unsigned coff = 0, slot_next = 0;
     auto dma_next = [&]() {
         unsigned char* dst = smem + slot_next + (wave << 10);
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (coff + lane16 + r * 4096)),
-                                             (__attribute__((address_space(3))) void*)(dst + r * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (coff + lane16 + r * 4096)),
-                                             (__attribute__((address_space(3))) void*)(dst + CH + r * 4096), 16, 0, 0);
+        for (int r = 0; r < RK; r++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (coff + lane16 + r * (NW * 1024))),
+                                             (__attribute__((address_space(3))) void*)(dst + r * (NW * 1024)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (coff + lane16 + r * (NW * 1024))),
+                                             (__attribute__((address_space(3))) void*)(dst + CH + r * (NW * 1024)), 16, 0, 0);
         }
         coff += CH;
         slot_next ^= STAGE;
@@ -65,12 +68,12 @@ __global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const Attn
     dma_next();
 
     // Q^T fragments parked in this lane's own LDS slots (registers are the scarce resource at three waves per SIMD)
-    unsigned char* qbuf = smem + kStages4 * STAGE + wave * 4096 + (hh << 10) + (ql << 4);
+    unsigned char* qbuf = smem + kStages4 * STAGE + wave * (KS << 11) + (hh << 10) + (ql << 4);
     {
         const bool qvalid = qrow < p.Sq;
         const unsigned char* qp = p.q + (((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32;
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < KS; s++) {
             v4i lo = *reinterpret_cast<const v4i*>(qp + s * 64);
             v4i hi = *reinterpret_cast<const v4i*>(qp + s * 64 + 16);
             if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
@@ -105,7 +108,9 @@ __global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const Attn
 
     for (int t = 0; t < n_wg; t++) {
         // Q^T fragments do not depend on the stage: request them before the barrier so their LDS latency hides behind it
-        const v8i qf = lds_read_frag(qbuf), qg = lds_read_frag(qbuf + (1 << 11));
+        v8i qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) qf[s] = lds_read_frag(qbuf + (s << 11));
         wait_vmcnt<0>();                  // this wave's pieces of stage t have landed
         __builtin_amdgcn_s_barrier();     // ... and everyone's; every wave is also done with stage t-1's slot
         if (t + 1 < n_wg) dma_next();
@@ -113,15 +118,15 @@ __global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const Attn
         const unsigned char* kbuf = smem + (t & 1) * STAGE + frag_lane_off;
         const unsigned char* vbuf = kbuf + CH;
         // ---- S^T = K.Q^T
-        const v8i ka = lds_read_frag(kbuf), kb = lds_read_frag(kbuf + (2 << 11));
-        const v8i kc = lds_read_frag(kbuf + (1 << 11)), kd = lds_read_frag(kbuf + (3 << 11));
         v16f s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
-        s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf, s0);
-        s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf, s1);
-        s0 = mfma_f8<QK_FMT, QK_FMT>(kc, qg, s0);
-        s1 = mfma_f8<QK_FMT, QK_FMT>(kd, qg, s1);
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const v8i ka = lds_read_frag(kbuf + ((0 * KS + s) << 11)), kb = lds_read_frag(kbuf + ((1 * KS + s) << 11));
+            s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf[s], s0);
+            s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf[s], s1);
+        }
         // the first two V fragments travel while the softmax runs (all four would not fit in 168 registers)
         const v8i vf0 = lds_read_frag(vbuf), vf1 = lds_read_frag(vbuf + (1 << 11));
         // ---- token-wise key scales, ragged-tail / causal mask (rare or cheap)
@@ -180,17 +185,20 @@ __global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const Attn
             pv[4 + j] = byte_exp4(s1[4 * j], s1[4 * j + 1], s1[4 * j + 2], s1[4 * j + 3], c8, off8);
         }
         // ---- O^T += V^T.P^T, row sums
-        const v8i vf2 = lds_read_frag(vbuf + (2 << 11)), vf3 = lds_read_frag(vbuf + (3 << 11));  // land under the first two MFMAs
         o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf0, pv, o[0]);
         o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf1, pv, o[1]);
-        o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf2, pv, o[2]);
-        o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf3, pv, o[3]);
+#pragma unroll
+        for (int m = 2; m < MB; m += 2) {  // the remaining fragments land under the MFMAs already issued
+            const v8i va = lds_read_frag(vbuf + (m << 11)), vb = lds_read_frag(vbuf + ((m + 1) << 11));
+            o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(va, pv, o[m]);
+            o[m + 1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vb, pv, o[m + 1]);
+        }
         lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
     }
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
-            const long wid = (long)blockIdx.x * kWaves4 + wave;
+            const long wid = (long)blockIdx.x * NW + wave;
             p.dbg_buf[2 * wid] = t1 - dbg_t0;
             p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
         }
@@ -231,21 +239,23 @@ __global__ __launch_bounds__(kWaves4 * 64, 3) void attn_fwd_kernel_v4(const Attn
     }
 }
 
-template <int FMT, bool CAUSAL, bool TOKEN>
-static int launch_v4_one(const AttnParams& p, int qb_lo, int qb_n, hipStream_t st) {
+template <int D, int FMT, bool CAUSAL, bool TOKEN>
+static int launch_v4_one(const AttnParams& p, int row_lo, hipStream_t st) {
+    constexpr int NW = V4Shape<D>::NW, ROWS = NW * kQPerWave;
+    const int qb_lo = row_lo / ROWS, qb_n = ceil_div(p.Sq, ROWS) - qb_lo;
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
-    const size_t lds = (size_t)kStages4 * 2 * 64 * 128 + (size_t)kWaves4 * 4096;  // K/V ring + parked Q^T fragments = 48 KiB
-    auto kern = attn_fwd_kernel_v4<FMT, FMT, CAUSAL, TOKEN>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves4 * 64), lds, st, p, qb_lo, qb_n);
+    const size_t lds = (size_t)kStages4 * 2 * 64 * D + (size_t)NW * kQPerWave * D;  // K/V ring + parked Q^T fragments
+    auto kern = attn_fwd_kernel_v4<D, FMT, FMT, CAUSAL, TOKEN>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n);
     return QATTN_OK;
 }
 
-// Rows [row_lo, Sq) of every head on the v4 kernel (row_lo a multiple of 128).  D = 128, byte-exponential, no LSE.
-int launch_attn_v4(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
-    const int qb_lo = row_lo / kQPerWG4, qb_n = ceil_div(p.Sq, kQPerWG4) - qb_lo;
+template <int D>
+static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
     const bool tok = scale_mode == QATTN_SCALE_TOKEN;
-#define QATTN_V4(F, C, T) return launch_v4_one<F, C, T>(p, qb_lo, qb_n, st)
+#define QATTN_V4(F, C, T) return launch_v4_one<D, F, C, T>(p, row_lo, st)
     if (fmt == QATTN_FMT_E4M3) {
         if (causal) { if (tok) QATTN_V4(QATTN_FMT_E4M3, true, true); else QATTN_V4(QATTN_FMT_E4M3, true, false); }
         else { if (tok) QATTN_V4(QATTN_FMT_E4M3, false, true); else QATTN_V4(QATTN_FMT_E4M3, false, false); }
@@ -254,6 +264,13 @@ int launch_attn_v4(const AttnParams& p, int fmt, int causal, int scale_mode, int
         else { if (tok) QATTN_V4(QATTN_FMT_E5M2, false, true); else QATTN_V4(QATTN_FMT_E5M2, false, false); }
     }
 #undef QATTN_V4
+}
+
+// Rows [row_lo, Sq) of every head on the v4 kernel (row_lo a multiple of 256).  Byte-exponential, no LSE.
+int launch_attn_v4(const AttnParams& p, int D, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
+    if (D == 64) return launch_v4_d<64>(p, fmt, causal, scale_mode, row_lo, st);
+    if (D == 128) return launch_v4_d<128>(p, fmt, causal, scale_mode, row_lo, st);
+    return launch_v4_d<256>(p, fmt, causal, scale_mode, row_lo, st);
 }
 
 }  // namespace qattn
