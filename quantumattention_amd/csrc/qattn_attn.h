@@ -82,5 +82,6 @@ int launch_attn_v1(const AttnParams& p, int D, int fmt, int causal, int scale_mo
 int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v3(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v4(const AttnParams& p, int D, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st);
+int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 
 }  // namespace qattn

@@ -312,18 +312,6 @@ static int launch_attn_v1_d(const AttnParams& p, int fmt, int causal, int scale_
 int launch_attn_v1(const AttnParams& pin, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
     AttnParams p = pin;
     p.v1_qb_n = 0;
-    // D = 64 / 256: q-blocks whose rows all see >= kTwoTermKeys keys take the byte-exponential v4 kernel (head-wise
-    // scales, no LSE, exact exponentials not requested); v1 keeps the two-term blocks and every other case.
-    if (p.use_v4 && D != 128 && scale_mode == QATTN_SCALE_HEAD && !p.exact_exp && p.lse == nullptr) {
-        int n_two;
-        if (causal) n_two = min(p.nqb, ceil_div(min(kTwoTermKeys, p.Skv), kQPerWG));
-        else n_two = p.Skv < kTwoTermKeys ? p.nqb : 0;
-        if (n_two < p.nqb) {
-            const int rc4 = launch_attn_v4(p, D, fmt, causal, scale_mode, n_two * kQPerWG, st);
-            if (rc4 != QATTN_OK || n_two == 0) return rc4;
-            p.v1_qb_n = n_two;
-        }
-    }
     if (D == 64) return launch_attn_v1_d<64>(p, fmt, causal, scale_mode, st);
     if (D == 128) return launch_attn_v1_d<128>(p, fmt, causal, scale_mode, st);
     return launch_attn_v1_d<256>(p, fmt, causal, scale_mode, st);

@@ -16,7 +16,11 @@ namespace qattn {
 constexpr int kStages4 = 2;
 // waves per workgroup: 4 (128 query rows; three workgroups per CU) for D <= 128, 8 for D = 256 (one workgroup per CU:
 // 64 + 64 KiB of LDS, O^T alone is 128 registers, so two waves per SIMD)
-template <int D> struct V4Shape { static constexpr int NW = D == 256 ? 8 : 4; static constexpr int WPS = D == 256 ? 2 : (D == 64 ? 4 : 3); };
+// LIGHT = head-wise byte-exponential kernel (the lean register budget); token-wise / exact variants get one wave less.
+template <int D, bool LIGHT> struct V4Shape {
+    static constexpr int NW = D == 256 ? 8 : 4;
+    static constexpr int WPS = D == 256 ? 2 : (D == 64 ? (LIGHT ? 4 : 3) : (LIGHT ? 3 : 2));
+};
 
 // 4 scores -> 4 e4m3 bytes of 2^x (see byte_group in qattn_attn_v2.hip: fma x4, v_cvt_pknorm_u16_f32 x2, v_perm_b32)
 __device__ __forceinline__ int byte_exp4(float s0, float s1, float s2, float s3, float c8, float off8) {
@@ -29,9 +33,12 @@ __device__ __forceinline__ int byte_exp4(float s0, float s1, float s2, float s3,
     return (int)__builtin_amdgcn_perm(ub, ua, 0x06040200u);
 }
 
-template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
-__global__ __launch_bounds__(V4Shape<D>::NW * 64, V4Shape<D>::WPS) void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n) {
-    constexpr int NW = V4Shape<D>::NW, kQPerWG4 = NW * kQPerWave;
+// BYTE: byte-exponential P + matrix-pipe row sums (default).  !BYTE: exact v_exp_f32, RNE fp8 conversion, fp32 row sums
+// (LSE output), and -- when `two` is set for the launch -- the hi+lo two-term P for rows that see few keys.
+template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE>
+__global__ __launch_bounds__((V4Shape<D, (BYTE && !TOKEN)>::NW * 64), (V4Shape<D, (BYTE && !TOKEN)>::WPS))
+void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, const int two) {
+    constexpr int NW = V4Shape<D, (BYTE && !TOKEN)>::NW, kQPerWG4 = NW * kQPerWave;
     constexpr int CH = 64 * D, STAGE = 2 * CH, MB = D / 32, KS = D / 64;
     constexpr int RK = CH / (NW * 1024);   // 1 KiB DMA pieces per wave for the K (and for the V) part of a stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(V4Shape<D>::NW * 64, V4Shape<D>::WPS) void attn_fwd
 #pragma unroll
         for (int w = 0; w < 8; w++) ones[w] = one;
     }
-    float m_run = -1.0e30f;
+    float m_run = -1.0e30f, l_run = 0.0f;
     constexpr float U16 = 1.0f / 65535.0f;
     const float c8 = (8.0f * U16) * c;
     const int frag_lane_off = (hh << 10) + (ql << 4);
@@ -172,28 +179,66 @@ __global__ __launch_bounds__(V4Shape<D>::NW * 64, V4Shape<D>::WPS) void attn_fwd
             for (int m = 0; m < MB; m++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) o[m][r] *= alpha;
-            lsum[0] *= alpha;
-            lsum[1] *= __shfl(alpha, (lane & 15) + 16);
+            if (BYTE) {
+                lsum[0] *= alpha;
+                lsum[1] *= __shfl(alpha, (lane & 15) + 16);
+            } else {
+                l_run *= alpha;
+            }
             m_run = m_new;
         }
-        // ---- P = e4m3 bytes of 2^(c*(s - m) + shift)
-        const float off8 = __builtin_fmaf((-8.0f * U16) * m_run, c, (8.0f * kPShiftByte + 56.0f + kByteBias) * U16);
-        v8i pv;
+        v8i pv, pl;
+        if (BYTE) {
+            // ---- P = e4m3 bytes of 2^(c*(s - m) + shift)
+            const float off8 = __builtin_fmaf((-8.0f * U16) * m_run, c, (8.0f * kPShiftByte + 56.0f + kByteBias) * U16);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            pv[j] = byte_exp4(s0[4 * j], s0[4 * j + 1], s0[4 * j + 2], s0[4 * j + 3], c8, off8);
-            pv[4 + j] = byte_exp4(s1[4 * j], s1[4 * j + 1], s1[4 * j + 2], s1[4 * j + 3], c8, off8);
+            for (int j = 0; j < 4; j++) {
+                pv[j] = byte_exp4(s0[4 * j], s0[4 * j + 1], s0[4 * j + 2], s0[4 * j + 3], c8, off8);
+                pv[4 + j] = byte_exp4(s1[4 * j], s1[4 * j + 1], s1[4 * j + 2], s1[4 * j + 3], c8, off8);
+            }
+        } else {
+            // ---- exact exponentials, RNE e4m3; optional residual term lo = fp8(p - hi); fp32 row sums
+            const float mc = kPShift - m_run * c;
+            float ls = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const v16f& sx = w < 4 ? s0 : s1;
+                const int j = w & 3;
+                float e[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[4 * j + i], c, mc)); ls += e[i]; }
+                int ph = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], 0);
+                ph = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2], e[3], ph);
+                pv[w] = ph;
+                int plo = 0;
+                if (two) {
+                    const float h0 = __builtin_amdgcn_cvt_f32_fp8(ph, 0), h1 = __builtin_amdgcn_cvt_f32_fp8(ph, 1);
+                    const float h2 = __builtin_amdgcn_cvt_f32_fp8(ph, 2), h3 = __builtin_amdgcn_cvt_f32_fp8(ph, 3);
+                    plo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h0, e[1] - h1, 0);
+                    plo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h2, e[3] - h3, plo);
+                }
+                pl[w] = plo;
+            }
+            l_run += ls;
         }
         // ---- O^T += V^T.P^T, row sums
         o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf0, pv, o[0]);
         o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf1, pv, o[1]);
+        if (!BYTE && two) {
+            o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf0, pl, o[0]);
+            o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf1, pl, o[1]);
+        }
 #pragma unroll
         for (int m = 2; m < MB; m += 2) {  // the remaining fragments land under the MFMAs already issued
             const v8i va = lds_read_frag(vbuf + (m << 11)), vb = lds_read_frag(vbuf + ((m + 1) << 11));
             o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(va, pv, o[m]);
             o[m + 1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vb, pv, o[m + 1]);
+            if (!BYTE && two) {
+                o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(va, pl, o[m]);
+                o[m + 1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vb, pl, o[m + 1]);
+            }
         }
-        lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+        if (BYTE) lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
     }
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -205,8 +250,14 @@ __global__ __launch_bounds__(V4Shape<D>::NW * 64, V4Shape<D>::WPS) void attn_fwd
     }
 
     // ---- epilogue
-    const float s0l = __shfl(lsum[0], lane & 15), s1l = __shfl(lsum[1], lane & 15);
-    const float l_tot = (lane & 16) ? s1l : s0l;
+    float l_tot;
+    if (BYTE) {
+        const float s0l = __shfl(lsum[0], lane & 15), s1l = __shfl(lsum[1], lane & 15);
+        l_tot = (lane & 16) ? s1l : s0l;
+    } else {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     const float sv = p.sv ? p.sv[kv_head] : 1.0f;
     const float inv = sv / l_tot;
     if (qrow < p.Sq) {
@@ -236,26 +287,28 @@ __global__ __launch_bounds__(V4Shape<D>::NW * 64, V4Shape<D>::WPS) void attn_fwd
                     *reinterpret_cast<h4*>(op + 32 * m + 8 * j + 4 * hh) = tv;
                 }
         }
+        if (!BYTE && p.lse && hh == 0)  // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l')
+            p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = 0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot);
     }
 }
 
-template <int D, int FMT, bool CAUSAL, bool TOKEN>
-static int launch_v4_one(const AttnParams& p, int row_lo, hipStream_t st) {
-    constexpr int NW = V4Shape<D>::NW, ROWS = NW * kQPerWave;
-    const int qb_lo = row_lo / ROWS, qb_n = ceil_div(p.Sq, ROWS) - qb_lo;
+template <int D, int FMT, bool CAUSAL, bool TOKEN, bool BYTE>
+static int launch_v4_one(const AttnParams& p, int row_lo, int row_hi, int two, hipStream_t st) {
+    constexpr int NW = V4Shape<D, (BYTE && !TOKEN)>::NW, ROWS = NW * kQPerWave;
+    const int qb_lo = row_lo / ROWS, qb_n = ceil_div(min(row_hi, p.Sq), ROWS) - qb_lo;
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
     const size_t lds = (size_t)kStages4 * 2 * 64 * D + (size_t)NW * kQPerWave * D;  // K/V ring + parked Q^T fragments
-    auto kern = attn_fwd_kernel_v4<D, FMT, FMT, CAUSAL, TOKEN>;
+    auto kern = attn_fwd_kernel_v4<D, FMT, FMT, CAUSAL, TOKEN, BYTE>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n, two);
     return QATTN_OK;
 }
 
-template <int D>
-static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
+template <int D, bool BYTE>
+static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, int row_hi, int two, hipStream_t st) {
     const bool tok = scale_mode == QATTN_SCALE_TOKEN;
-#define QATTN_V4(F, C, T) return launch_v4_one<D, F, C, T>(p, row_lo, st)
+#define QATTN_V4(F, C, T) return launch_v4_one<D, F, C, T, BYTE>(p, row_lo, row_hi, two, st)
     if (fmt == QATTN_FMT_E4M3) {
         if (causal) { if (tok) QATTN_V4(QATTN_FMT_E4M3, true, true); else QATTN_V4(QATTN_FMT_E4M3, true, false); }
         else { if (tok) QATTN_V4(QATTN_FMT_E4M3, false, true); else QATTN_V4(QATTN_FMT_E4M3, false, false); }
@@ -266,11 +319,34 @@ static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode,
 #undef QATTN_V4
 }
 
-// Rows [row_lo, Sq) of every head on the v4 kernel (row_lo a multiple of 256).  Byte-exponential, no LSE.
+// Rows [row_lo, Sq) of every head on the byte-exponential v4 kernel (row_lo a multiple of 256).  No LSE.
 int launch_attn_v4(const AttnParams& p, int D, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
-    if (D == 64) return launch_v4_d<64>(p, fmt, causal, scale_mode, row_lo, st);
-    if (D == 128) return launch_v4_d<128>(p, fmt, causal, scale_mode, row_lo, st);
-    return launch_v4_d<256>(p, fmt, causal, scale_mode, row_lo, st);
+    if (D == 64) return launch_v4_d<64, true>(p, fmt, causal, scale_mode, row_lo, p.Sq, 0, st);
+    if (D == 128) return launch_v4_d<128, true>(p, fmt, causal, scale_mode, row_lo, p.Sq, 0, st);
+    return launch_v4_d<256, true>(p, fmt, causal, scale_mode, row_lo, p.Sq, 0, st);
+}
+
+// The whole forward for D = 64 / 256 (the hand-scheduled v2 kernel exists for D = 128 only): rows that see fewer than
+// kTwoTermKeys keys run the exact two-term variant, the rest the byte-exponential one (or the exact one-term variant when
+// an LSE output or exact exponentials are requested).
+int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
+    if (D != 64 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
+    int rows_two;  // leading rows (a multiple of 256) that need the two-term P
+    if (causal) rows_two = min(ceil_div(p.Sq, 256), ceil_div(min(kTwoTermKeys, p.Skv), 256)) * 256;
+    else rows_two = p.Skv < kTwoTermKeys ? ceil_div(p.Sq, 256) * 256 : 0;
+    const bool byte_exp = !p.exact_exp && p.lse == nullptr;
+    int rc = QATTN_OK;
+    if (rows_two < p.Sq) {
+        if (D == 64) rc = byte_exp ? launch_v4_d<64, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
+                                   : launch_v4_d<64, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
+        else rc = byte_exp ? launch_v4_d<256, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
+                           : launch_v4_d<256, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
+    }
+    if (rc == QATTN_OK && rows_two > 0) {
+        if (D == 64) rc = launch_v4_d<64, false>(p, fmt, causal, scale_mode, 0, rows_two, 1, st);
+        else rc = launch_v4_d<256, false>(p, fmt, causal, scale_mode, 0, rows_two, 1, st);
+    }
+    return rc;
 }
 
 }  // namespace qattn

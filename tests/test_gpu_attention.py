@@ -75,6 +75,10 @@ CASES = [
     (1, 1, 1, 1, 1, 128, False, "e4m3", "head-wise", torch.bfloat16),           # single token
     (1, 1, 1, 3, 70, 64, False, "e4m3", "head-wise", torch.bfloat16),
     (3, 5, 5, 300, 300, 128, True, "e4m3", "head-wise", torch.bfloat16),        # B*H not a multiple of 8
+    (1, 2, 2, 1100, 1100, 64, True, "e4m3", "token-wise", torch.bfloat16),      # D = 64 / 256: every mode of the templated kernel
+    (1, 2, 2, 1024, 1024, 256, False, "e5m2", "token-wise", torch.bfloat16),
+    (1, 4, 2, 2100, 2100, 256, True, "e4m3", "head-wise", torch.bfloat16),      # two-term + byte launches, GQA
+    (2, 4, 4, 1500, 1200, 64, False, "e5m2", "head-wise", torch.float16),
 ]
 
 
