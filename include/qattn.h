@@ -57,7 +57,7 @@ extern "C" {
 #define QATTN_LAYOUT_VFRAG 2
 /* fragment layouts of a 16-bit (bf16/fp16) K or V tensor for the 16-bit sibling path (16-byte pieces of 8 elements):
  *   QATTN_LAYOUT_K16FRAG chunk = [t:2][s:D/16][hh:2][key:32][8 elts], piece = K[64c + 32t + key][16s + 8hh + (0..7)]
- *   QATTN_LAYOUT_V16FRAG chunk = [m:D/32][t:2][s:2][hh:2][d:32][8 elts],
+ *   QATTN_LAYOUT_V16FRAG chunk = [t:2][m:D/32][s:2][hh:2][d:32][8 elts],
  *                        element j of a piece = V[64c + 32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]               */
 #define QATTN_LAYOUT_K16FRAG 3
 #define QATTN_LAYOUT_V16FRAG 4

@@ -8,10 +8,11 @@
 //
 // K and V are re-laid by qattn_pack16 into fragment order (64-key chunks, 16-byte pieces):
 //   K16FRAG chunk = [t:2][s:D/16][hh:2][key:32][8 x 16 bit]   piece = K[64c + 32t + key][16s + 8hh + (0..7)]
-//   V16FRAG chunk = [m:D/32][t:2][s:2][hh:2][d:32][8 x 16 bit] piece j = V[64c + 32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]
-// so a chunk is a linear LDS-DMA copy and every MFMA A operand is one conflict-free ds_read_b128.
-// Structure: 8 waves x 32 rows, 3-stage LDS ring, one barrier per chunk (the first, non-pipelined fp8 structure);
-// exact exp2, fp32 row sums, deferred rescale.
+//   V16FRAG chunk = [t:2][m:D/32][s:2][hh:2][d:32][8 x 16 bit] piece j = V[64c + 32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]
+// so every 32-key tile (t) of K and of V is one linear LDS-DMA copy and every MFMA A operand is one conflict-free
+// ds_read_b128.  Exact exp2, fp32 row sums, deferred rescale; structure described at the kernel.
+#include <cstdlib>
+
 #include "qattn_attn.h"
 
 namespace qattn {
@@ -24,11 +25,17 @@ template <> struct T16<QATTN_FMT_BF16> {
     typedef __bf16 elt;
     typedef bf16x8 vec;
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4f mfma16(vec a, vec b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static constexpr unsigned kOne2 = 0x3f803f80u;                   // two 1.0 elements
+    static constexpr float kBitsPerOctave = 128.0f, kExpBias = 127.0f;  // bits of 2^x = (x + 127) * 2^7 (+ mantissa)
 };
 template <> struct T16<QATTN_FMT_FP16> {
     typedef _Float16 elt;
     typedef f16x8 vec;
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4f mfma16(vec a, vec b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static constexpr unsigned kOne2 = 0x3c003c00u;
+    static constexpr float kBitsPerOctave = 1024.0f, kExpBias = 15.0f;
 };
 
 struct Attn16Params {
@@ -38,34 +45,35 @@ struct Attn16Params {
     void* out;
     float* lse;
     int B, Hq, Hkv, Sq, Skv;
-    int nqb, nchunks, xcd_remap;
+    int nqb, ntiles, xcd_remap;
     float sm_log2e;
 };
 
-constexpr int kStages16 = 3;
+constexpr int kWaves16 = 4;                        // 128 query rows per workgroup
+constexpr int kQPerWG16 = kWaves16 * kQPerWave;
+constexpr int kStages16 = 2;
 
-template <int D>
-__device__ __forceinline__ void stage16(const unsigned char* kg, const unsigned char* vg, unsigned char* lds_stage, int wave, int lane) {
-    constexpr int CH = 64 * D * 2;                       // bytes of one K (or V) chunk
-    constexpr int ROUNDS = 2 * CH / (kThreads * 16);
-    const int wave_base = wave << 10;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const int o = r * (kThreads * 16) + wave_base;
-        const unsigned char* src = (o < CH ? kg + o : vg + (o - CH)) + (lane << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_stage + o), 16, 0, 0);
-    }
-}
+// Structure (same idea as qattn_attn_v4.hip): every wave runs the plain sequence QK^T -> max / rescale -> exponentials -> PV on
+// 32-key tiles with S, P single-buffered and Q^T in registers (<= 168 VGPRs); a workgroup is 4 waves x 32 rows with a
+// two-stage ring of {K tile, V tile} (32 KiB for D = 128), so a CU holds three independent workgroups and each SIMD
+// interleaves three waves that are never phase-aligned.  One barrier per tile.
+// FAST: the 16-bit pattern of 2^x is taken as (x + bias) * 2^mantissa_bits (Schraudolph's linear-mantissa exponential:
+// one v_fma_f32 per score + one v_cvt_pknorm_u16_f32 per pair, which already packs the PV B operand; relative error
+// 1.8 % rms, -3.9 .. +2.0 %), and the row sums of the SAME approximated weights come from two small
+// v_mfma_f32_16x16x32 per tile with a two-row selector A operand, so numerator and denominator stay consistent.  With the
+// exact path (v_exp_f32 + fp32 sums) the kernel is VALU-bound.  Used where a row sees >= kTwoTermKeys keys and no LSE
+// is requested; the exact instantiation covers the rest.
+constexpr float kFastExpBias = -0.0575f;  // centres the (1+f)/2^f mantissa error
 
-template <int D, int FMT16, bool CAUSAL>
-__global__ __launch_bounds__(kThreads, 2) void attn16_fwd_kernel(const Attn16Params p) {
+template <int D, int FMT16, bool CAUSAL, bool FAST>
+__global__ __launch_bounds__(kWaves16 * 64, 3) void attn16_fwd_kernel(const Attn16Params p, const int qb_lo, const int qb_n) {
     typedef typename T16<FMT16>::vec vec16;
     typedef typename T16<FMT16>::elt elt16;
-    constexpr int CH = 64 * D * 2, STAGE = 2 * CH;
-    constexpr int KS = D / 16;   // QK^T k-steps
-    constexpr int MB = D / 32;   // O^T row blocks
-    constexpr int ROUNDS = 2 * CH / (kThreads * 16);
+    constexpr int TB = 32 * D * 2;       // bytes of one 32-key K (or V) tile
+    constexpr int STAGE = 2 * TB;
+    constexpr int KS = D / 16;           // QK^T k-steps
+    constexpr int MB = D / 32;           // O^T row blocks
+    constexpr int RK = TB / (kWaves16 * 1024);  // 1 KiB DMA pieces per wave for the K (and the V) tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,23 +82,38 @@ __global__ __launch_bounds__(kThreads, 2) void attn16_fwd_kernel(const Attn16Par
     int bid = blockIdx.x, head, qb;
     if (p.xcd_remap) {
         const int xcd = bid & 7, idx = bid >> 3;
-        head = xcd * ((p.B * p.Hq) >> 3) + idx / p.nqb;
-        qb = idx % p.nqb;
+        head = xcd * ((p.B * p.Hq) >> 3) + idx / qb_n;
+        qb = idx % qb_n;
     } else {
-        head = bid / p.nqb;
-        qb = bid % p.nqb;
+        head = bid / qb_n;
+        qb = bid % qb_n;
     }
-    if (CAUSAL) qb = p.nqb - 1 - qb;
+    if (CAUSAL) qb = qb_n - 1 - qb;
+    qb += qb_lo;
     const int b = head / p.Hq, h = head % p.Hq;
     const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
-    const int q0_wg = qb * kQPerWG, q0 = q0_wg + wave * kQPerWave, qrow = q0 + ql;
-    const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
-    const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
-    int nloop = p.nchunks;
-    if (CAUSAL) nloop = min(nloop, (min(q0_wg + kQPerWG, p.Sq) - 1) / 64 + 1);
+    const int q0_wg = qb * kQPerWG16, q0 = q0_wg + wave * kQPerWave, qrow = q0 + ql;
+    const long head_bytes = (long)ceil_div(p.Skv, 64) * 2 * TB;   // the packed tensors pad S to a multiple of 64 keys
+    const unsigned char* kg_w = p.k + kv_head * head_bytes + (wave << 10);
+    const unsigned char* vg_w = p.v + kv_head * head_bytes + (wave << 10);
+    const int n_wg = CAUSAL ? min(p.ntiles, (min(q0_wg + kQPerWG16, p.Sq) - 1) / 32 + 1) : p.ntiles;
+    const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 32 + 1) : p.ntiles;
 
-    stage16<D>(kg, vg, smem, wave, lane);
-    if (nloop > 1) stage16<D>(kg + CH, vg + CH, smem + STAGE, wave, lane);
+    const unsigned lane16 = (unsigned)lane << 4;
+    unsigned toff = 0, slot_next = 0;
+    auto dma_next = [&]() {
+        unsigned char* dst = smem + slot_next + (wave << 10);
+#pragma unroll
+        for (int r = 0; r < RK; r++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (toff + lane16 + r * (kWaves16 * 1024))),
+                                             (__attribute__((address_space(3))) void*)(dst + r * (kWaves16 * 1024)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (toff + lane16 + r * (kWaves16 * 1024))),
+                                             (__attribute__((address_space(3))) void*)(dst + TB + r * (kWaves16 * 1024)), 16, 0, 0);
+        }
+        toff += TB;
+        slot_next ^= STAGE;
+    };
+    dma_next();
 
     // Q^T fragments: lane (q, hh) holds Q[q][16s + 8hh + (0..7)] for every k-step s
     vec16 qf[KS];
@@ -110,84 +133,126 @@ __global__ __launch_bounds__(kThreads, 2) void attn16_fwd_kernel(const Attn16Par
     for (int m = 0; m < MB; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
+    float m_run = -1.0e30f, l_run = 0.0f;
     const int frag_lane_off = (hh << 9) + (ql << 4);
+    v4f lsum = {0.0f, 0.0f, 0.0f, 0.0f};
+    vec16 ones;  // FAST: A of the row-sum MFMA: lane = row (l & 15) + 16 * k-group; rows 0 / 1 are 1.0 on even / odd k-groups
+    {
+        const int row = lane & 15, kg = lane >> 4;
+        const unsigned one = ((row == 0 && !(kg & 1)) || (row == 1 && (kg & 1))) ? T16<FMT16>::kOne2 : 0u;
+        const unsigned w4[4] = {one, one, one, one};
+        __builtin_memcpy(&ones, w4, 16);
+    }
+    constexpr float U16 = 1.0f / 65535.0f, BPO = T16<FMT16>::kBitsPerOctave;
+    const float cfast = (BPO * U16) * c;
 
-    for (int c_idx = 0; c_idx < nloop; c_idx++) {
-        if (c_idx + 1 < nloop) { if (ROUNDS == 2) wait_vmcnt<2>(); else wait_vmcnt<4>(); }
-        else wait_vmcnt<0>();
+    for (int t = 0; t < n_wg; t++) {
+        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (c_idx + 2 < nloop)
-            stage16<D>(kg + (long)(c_idx + 2) * CH, vg + (long)(c_idx + 2) * CH, smem + ((c_idx + 2) % kStages16) * STAGE, wave, lane);
-        const int k0 = c_idx * 64;
-        if (CAUSAL && k0 > q0 + kQPerWave - 1) continue;  // fully masked for this wave
-        const unsigned char* kbuf = smem + (c_idx % kStages16) * STAGE + frag_lane_off;
-        const unsigned char* vbuf = kbuf + CH;
-
-        // ---- S^T = K . Q^T (two 32-key tiles, D/16 k-steps each)
-        v16f s0, s1;
+        if (t + 1 < n_wg) dma_next();
+        if (t >= n_w) continue;  // causal: this wave's rows end before tile t
+        const unsigned char* kbuf = smem + (t & 1) * STAGE + frag_lane_off;
+        const unsigned char* vbuf = kbuf + TB;
+        // ---- S^T (32 keys x 32 queries) = K.Q^T
+        v16f sc;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
+        for (int r = 0; r < 16; r++) sc[r] = 0.0f;
+        // all K fragments of the tile are requested before the MFMA chain starts (left alone the compiler re-uses one
+        // register quad and waits for every ds_read right before the MFMA that consumes it)
+        vec16 ka[KS];
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const vec16 ka = *reinterpret_cast<const vec16*>(kbuf + ((0 * KS + s) << 10));
-            const vec16 kb = *reinterpret_cast<const vec16*>(kbuf + ((1 * KS + s) << 10));
-            s0 = T16<FMT16>::mfma(ka, qf[s], s0);
-            s1 = T16<FMT16>::mfma(kb, qf[s], s1);
-        }
-        float sc[32];
+        for (int s = 0; s < KS; s++) ka[s] = *reinterpret_cast<const vec16*>(kbuf + (s << 10));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; r++) { sc[r] = s0[r]; sc[16 + r] = s1[r]; }
-        const bool need_mask = (k0 + 64 > p.Skv) || (CAUSAL && k0 + 63 > q0);
-        if (need_mask) {
+        for (int s = 0; s < KS; s++) sc = T16<FMT16>::mfma(ka[s], qf[s], sc);
+        __builtin_amdgcn_sched_barrier(0);
+        // the first half of the V fragments travels while the softmax runs
+        constexpr int NV = 2 * MB, NV0 = NV < 4 ? NV : 4;
+        vec16 va[NV];
 #pragma unroll
-            for (int r = 0; r < 32; r++) {
-                const int key = k0 + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * hh;
+        for (int i = 0; i < NV0; i++) va[i] = *reinterpret_cast<const vec16*>(vbuf + (i << 10));
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = t * 32;
+        const bool need_mask = (k0 + 32 > p.Skv) || (CAUSAL && k0 + 31 > q0);
+        if (__builtin_expect(need_mask, 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 const bool dead = key >= p.Skv || (CAUSAL && key > qrow);
                 sc[r] = dead ? -INFINITY : sc[r];
             }
         }
-        float mx = sc[0];
+        float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
-        for (int r = 1; r < 32; r++) mx = fmaxf(mx, sc[r]);
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+        mx = fmaxf(mx, sc[15]);
         {
             auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        const float m_new = fmaxf(m_run, mx);
-        if (__any((m_new - m_run) * c > kRescaleThr)) {  // deferred rescale (always on the first chunk)
-            const float alpha = (m_new == m_run) ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        if (__builtin_expect(__any((mx - m_run) * c > kRescaleThr) != 0, 0)) {  // deferred rescale (always on the first tile)
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
 #pragma unroll
             for (int m = 0; m < MB; m++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) o[m][r] *= alpha;
-            l_run *= alpha;
+            if (FAST) {
+                lsum[0] *= alpha;
+                lsum[1] *= __shfl(alpha, (lane & 15) + 16);
+            } else {
+                l_run *= alpha;
+            }
             m_run = m_new;
         }
-        const float mc = -m_run * c;
-        // ---- P = exp2(c*s - c*m) in fp32, row sums in fp32, then 16-bit conversion -> PV B operands
-        float pr[32];
-        float ls = 0.0f;
+        vec16 pb[2];
+        if (FAST) {
+            // ---- P bit patterns straight from the scores; row sums on the matrix pipe
+            const float off = __builtin_fmaf((-BPO * U16) * m_run, c, (BPO * (T16<FMT16>::kExpBias + kFastExpBias)) * U16);
 #pragma unroll
-        for (int r = 0; r < 32; r++) { pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, mc)); ls += pr[r]; }
-        l_run += ls;
-        vec16 pb[4];  // [tile t][k-step s'] -> index 2t + s'
+            for (int i = 0; i < 2; i++) {
+                unsigned w4[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    const us2 pk = __builtin_amdgcn_cvt_pknorm_u16(__builtin_fmaf(sc[8 * i + 2 * j], cfast, off),
+                                                                   __builtin_fmaf(sc[8 * i + 2 * j + 1], cfast, off));
+                    __builtin_memcpy(&w4[j], &pk, 4);
+                }
+                __builtin_memcpy(&pb[i], w4, 16);
+            }
+            lsum = T16<FMT16>::mfma16(ones, pb[0], lsum);
+            lsum = T16<FMT16>::mfma16(ones, pb[1], lsum);
+        } else {
+            // ---- P = exp2(c*s - c*m) in fp32, row sums in fp32, 16-bit conversion -> the two PV k-steps' B operands
+            const float mc = -m_run * c;
+            float ls = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; j++) pb[i][j] = (elt16)pr[8 * i + j];
-        // ---- O^T += V^T . P^T
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[8 * i + j], c, mc));
+                    ls += e;
+                    pb[i][j] = (elt16)e;
+                }
+            l_run += ls;
+        }
+        // ---- O^T += V^T.P^T (the second half of the V fragments lands under the first MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = NV0; i < NV; i++) va[i] = *reinterpret_cast<const vec16*>(vbuf + (i << 10));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MB; m++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const vec16 va = *reinterpret_cast<const vec16*>(vbuf + ((m * 4 + i) << 10));
-                o[m] = T16<FMT16>::mfma(va, pb[i], o[m]);
-            }
+            for (int i = 0; i < 2; i++) o[m] = T16<FMT16>::mfma(va[m * 2 + i], pb[i], o[m]);
     }
 
     float l_tot;
-    {
+    if (FAST) {
+        const float s0l = __shfl(lsum[0], lane & 15), s1l = __shfl(lsum[1], lane & 15);
+        l_tot = (lane & 16) ? s1l : s0l;
+    } else {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
@@ -199,10 +264,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn16_fwd_kernel(const Attn16Par
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 typedef elt16 e4 __attribute__((ext_vector_type(4)));
-                e4 t;
+                e4 tv;
 #pragma unroll
-                for (int i = 0; i < 4; i++) t[i] = (elt16)(o[m][4 * j + i] * inv);
-                *reinterpret_cast<e4*>(op + 32 * m + 8 * j + 4 * hh) = t;
+                for (int i = 0; i < 4; i++) tv[i] = (elt16)(o[m][4 * j + i] * inv);
+                *reinterpret_cast<e4*>(op + 32 * m + 8 * j + 4 * hh) = tv;
             }
         if (p.lse && hh == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = 0.6931471805599453f * (m_run * c) + __logf(l_tot);
     }
@@ -236,9 +301,9 @@ __global__ __launch_bounds__(256) void pack16_tile_kernel(const uint4* __restric
             dst[0] = raw.x; dst[1] = raw.y; dst[2] = raw.z; dst[3] = raw.w;
         }
         __syncthreads();
-        // output vector n: [m:D/32][t:2][s:2][hh:2][d:32]; its element j = V[32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]
+        // output vector n: [t:2][m:D/32][s:2][hh:2][d:32]; its element j = V[32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]
         for (int n = tid; n < 64 * VPR; n += 256) {
-            const int dl = n & 31, hh2 = (n >> 5) & 1, s = (n >> 6) & 1, t = (n >> 7) & 1, m = n >> 8;
+            const int dl = n & 31, hh2 = (n >> 5) & 1, s = (n >> 6) & 1, m = (n >> 7) % (D / 32), t = n / (128 * (D / 32));
             unsigned short e[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -252,20 +317,31 @@ __global__ __launch_bounds__(256) void pack16_tile_kernel(const uint4* __restric
     }
 }
 
+template <int D, int FMT16, bool CAUSAL, bool FAST>
+static int launch16_one(const Attn16Params& p, int row_lo, int row_hi, hipStream_t st) {
+    const int qb_lo = row_lo / kQPerWG16, qb_n = ceil_div(min(row_hi, p.Sq), kQPerWG16) - qb_lo;
+    if (qb_n <= 0) return QATTN_OK;
+    const int grid = p.B * p.Hq * qb_n;
+    const size_t lds = (size_t)kStages16 * 2 * 32 * D * 2;
+    hipLaunchKernelGGL((attn16_fwd_kernel<D, FMT16, CAUSAL, FAST>), dim3(grid), dim3(kWaves16 * 64), lds, st, p, qb_lo, qb_n);
+    return QATTN_OK;
+}
+
 template <int D, int FMT16>
 static int launch16(const Attn16Params& p, int causal, hipStream_t st) {
-    const int grid = p.B * p.Hq * p.nqb;
-    const size_t lds = (size_t)kStages16 * 2 * 64 * D * 2;
-    if (causal) {
-        auto kern = attn16_fwd_kernel<D, FMT16, true>;
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
-    } else {
-        auto kern = attn16_fwd_kernel<D, FMT16, false>;
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
-    }
-    return QATTN_OK;
+    // rows that see fewer than kTwoTermKeys keys, and every row when an LSE output or exact exponentials are requested,
+    // take the exact instantiation
+    static const bool force_exact = getenv("QATTN_EXACT_EXP") && atoi(getenv("QATTN_EXACT_EXP")) != 0;
+    int rows_exact;
+    if (force_exact || p.lse != nullptr) rows_exact = p.Sq;
+    else if (causal) rows_exact = min(p.Sq, ceil_div(min(kTwoTermKeys, p.Skv), kQPerWG16) * kQPerWG16);
+    else rows_exact = p.Skv < kTwoTermKeys ? p.Sq : 0;
+    int rc = QATTN_OK;
+    if (rows_exact < p.Sq)
+        rc = causal ? launch16_one<D, FMT16, true, true>(p, rows_exact, p.Sq, st) : launch16_one<D, FMT16, false, true>(p, rows_exact, p.Sq, st);
+    if (rc == QATTN_OK && rows_exact > 0)
+        rc = causal ? launch16_one<D, FMT16, true, false>(p, 0, rows_exact, st) : launch16_one<D, FMT16, false, false>(p, 0, rows_exact, st);
+    return rc;
 }
 
 }  // namespace qattn
@@ -304,8 +380,8 @@ extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const 
     p.q = (const unsigned char*)q; p.k = (const unsigned char*)k16; p.v = (const unsigned char*)v16;
     p.out = out; p.lse = lse;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
-    p.nqb = ceil_div(Sq, kQPerWG);
-    p.nchunks = ceil_div(Skv, 64);
+    p.nqb = ceil_div(Sq, kQPerWG16);
+    p.ntiles = ceil_div(Skv, 32);
     p.xcd_remap = ((B * Hq) % 8 == 0) ? 1 : 0;
     const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
     p.sm_log2e = sm * 1.4426950408889634f;

@@ -34,7 +34,7 @@ def unpack16(buf: np.ndarray, layout: int, B: int, H: int, S: int, D: int) -> np
     else:
         t, s, jh, hh, jl = key >> 5, (key >> 4) & 1, (key >> 3) & 1, (key >> 2) & 1, key & 3
         m, dl = d >> 5, d & 31
-        off = ((((((m * 2 + t) * 2 + s) * 2 + hh) * 32 + dl) * 8) + 4 * jh + jl)
+        off = ((((((t * (D // 32) + m) * 2 + s) * 2 + hh) * 32 + dl) * 8) + 4 * jh + jl)
     return x[..., off].reshape(B, H, Sp, D)
 
 
@@ -90,7 +90,8 @@ def test_16bit_kernel_vs_oracle(case):
     kf = _native.pack16(k.cuda(), _native.LAYOUT_K16FRAG)
     vf = _native.pack16(v.cuda(), _native.LAYOUT_V16FRAG)
     out2, lse = _native.attention_forward_16(q.cuda(), kf, vf, Hkv=Hkv, Skv=Skv, is_causal=causal, return_lse=True)
-    assert torch.equal(out2, out)
+    mx2, _ = err_stats(out_to_f32(out2), ref)  # asking for the LSE selects the exact-exponential instantiation
+    assert mx2 < tol_for(ref), mx2
     np.testing.assert_allclose(lse.cpu().numpy(), ref_lse, rtol=0, atol=2e-3)
 
 
