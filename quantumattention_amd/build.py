@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libqattn_hip.so")
-SOURCES = ["qattn_quant.hip", "qattn_attn_v1.hip", "qattn_attn_v2.hip", "qattn_attn_v3.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip"]
+SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v3.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip"]
 ARCH = "gfx950"
 # one-wave-per-SIMD kernels (up to 512 registers): keep MFMA results that the VALU reads in architectural VGPRs instead
 # of the default AGPR-form MFMAs, which cost ~146 v_accvgpr copies per iteration

@@ -52,10 +52,9 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     p.q = (const unsigned char*)q8; p.k = (const unsigned char*)k8; p.v = (const unsigned char*)v8;
     p.out = out; p.lse = lse; p.sq = scale_q; p.sk = scale_k; p.sv = scale_v;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
-    const bool use_v1 = kernel_variant() == 1;
-    const bool use_v4_full = !use_v1 && D != 128;  // D = 64 / 256: the templated three-waves kernel covers every case
-    const bool use_v3 = !use_v1 && kernel_variant() == 3;
-    p.waves = (use_v1 || use_v3 || use_v4_full) ? kWaves : env_int("QATTN_V2_WAVES", 8);  // v1 and v3 workgroups also cover 256 rows
+    const bool use_v4_full = D != 128;  // D = 64 / 256: the templated three-waves kernel covers every case
+    const bool use_v3 = !use_v4_full && kernel_variant() == 3;
+    p.waves = (use_v3 || use_v4_full) ? kWaves : env_int("QATTN_V2_WAVES", 8);  // v3 workgroups also cover 256 rows
     p.lds_pad = env_int("QATTN_V2_LDS", 0);
     p.dbg = env_int("QATTN_V2_DBG", 0);
     p.dbg_buf = nullptr;
@@ -74,11 +73,9 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     p.sm_log2e = sm * 1.4426950408889634f;
     p.exact_exp = exact_exp();
     p.use_v4 = kernel_variant() == 4 ? 1 : 0;
-    p.v1_qb_n = 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (use_v1) rc = launch_attn_v1(p, D, qk_fmt, is_causal, scale_mode, st);
-    else if (use_v4_full) rc = launch_attn_v4_full(p, D, qk_fmt, is_causal, scale_mode, st);
+    if (use_v4_full) rc = launch_attn_v4_full(p, D, qk_fmt, is_causal, scale_mode, st);
     else if (use_v3) rc = launch_attn_v3(p, D, qk_fmt, is_causal, scale_mode, st);
     else rc = launch_attn_v2(p, D, qk_fmt, is_causal, scale_mode, st);
     if (rc != QATTN_OK) return rc;

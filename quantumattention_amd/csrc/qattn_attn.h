@@ -35,7 +35,6 @@ struct AttnParams {
     int lds_pad;     // development: force this dynamic-LDS size (occupancy experiments), 0 = natural
     unsigned long long* dbg_buf;  // development: per-wave {cycles, realtime ticks} of the KV sweep when dbg & 16
     int dbg;         // development: 16 = stamp per-wave sweep cycles into dbg_buf
-    int v1_qb_n;     // q-blocks (of 256 rows) the v1 launch covers, 0 = all (the rest runs on v4 for D = 64 / 256)
     int use_v4;      // 1: head-wise one-term byte-exponential q-blocks run on the three-waves-per-SIMD kernel (qattn_attn_v4.hip)
 };
 
@@ -78,7 +77,6 @@ __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool cau
     if (causal) qb = nqb - 1 - qb;  // heaviest query blocks first
 }
 
-int launch_attn_v1(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v3(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v4(const AttnParams& p, int D, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st);
