@@ -240,3 +240,39 @@ def test_torch_compile_traces_the_ops_as_opaque_calls(backend):
     for S in (256, 384):
         q, k, v = (torch.randn(1, 4, S, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
         assert torch.equal(cf(q, k, v), f(q, k, v))
+
+
+def test_c_abi_error_codes_instead_of_exceptions():
+    """include/qattn.h: every entry returns a negative QATTN_ERR_* code (never throws, never launches) on bad arguments --
+    the counterpart of the reference launcher's TORCH_CHECKs (tk/attention.py:362-415)."""
+    import ctypes
+
+    L = _native.lib()
+    q8 = torch.zeros(1, 2, 64, 128, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(1, 2, 64, 128, dtype=torch.bfloat16, device="cuda")
+    sc = torch.ones(1, 2, dtype=torch.float32, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    f0 = ctypes.c_float(0.0)
+
+    def attn(D=128, Hq=2, Hkv=2, qk=0, vf=0, of=2, mode=0, q=q8):
+        return L.qattn_fp8_attention_forward(P(q) if q is not None else None, P(q8), P(q8), P(out), None, P(sc), P(sc), None,
+                                             1, Hq, Hkv, 64, 64, D, qk, vf, of, mode, 0, f0, None)
+
+    assert attn() == 0
+    assert attn(D=96) == -2 and L.qattn_strerror(-2) is not None       # head_dim not in {64,128,256} (nn.py:45-49)
+    assert attn(Hq=3, Hkv=2) == -2                                     # Hq % Hkv != 0
+    assert attn(qk=2) == -3 and attn(vf=1) == -3 and attn(of=0) == -3  # formats
+    assert attn(mode=7) == -1 and attn(q=None) == -1                   # enum / NULL pointer
+    x = torch.zeros(1, 2, 64, 128, dtype=torch.bfloat16, device="cuda")
+    x8 = torch.zeros(1, 2, 64, 128, dtype=torch.uint8, device="cuda")
+    s = torch.zeros(1, 2, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(4, dtype=torch.uint8, device="cuda")
+    quant = lambda D=128, in_fmt=2, out_fmt=0, ws_bytes=8: L.qattn_quant_fp8(P(x), in_fmt, P(x8), P(s), 1, 2, 64, D, out_fmt, 0, 0, 0,
+                                                                              P(ws), ctypes.c_size_t(ws_bytes), None)
+    assert quant(ws_bytes=4) == -4                                      # workspace too small (needs 2 heads x 4 bytes)
+    assert quant(D=100) == -2 and quant(in_fmt=0) == -3 and quant(out_fmt=2) == -3
+    assert L.qattn_pack16(P(x), P(x8), 1, 2, 64, 256, 3, None) == -2    # the 16-bit path has D in {64,128}
+    assert L.qattn_attention_forward_16(P(x), P(x), P(x), P(out), None, 1, 2, 2, 64, 64, 128, 0, 0, f0, None) == -3
+    torch.cuda.synchronize()
+    for code in (0, -1, -2, -3, -4, -5, -6):
+        assert len(L.qattn_strerror(code)) > 0
