@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define QATTN_ABI_VERSION 2
+#define QATTN_ABI_VERSION 3
 
 /* element formats */
 #define QATTN_FMT_E4M3 0 /* OCP float8_e4m3fn  (torch.float8_e4m3fn) */
@@ -134,6 +134,19 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
                                 const float* scale_q, const float* scale_k, const float* scale_v, int B, int Hq,
                                 int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt, int scale_mode,
                                 int is_causal, float sm_scale, void* stream);
+
+/*
+ * The whole step of `_fp8_attention_wrapper` for 16-bit inputs (nn.py:394-430: quantise q and k, then the fp8 op) in one
+ * call: pre-pass (qattn_quant_qkv_fp8 semantics) + attention (qattn_fp8_attention_forward semantics, no LSE) on `stream`.
+ * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
+ * qattn_quant_qkv_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16, head-wise) the
+ * pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read and one write
+ * of Q; results are bit-identical to the two separate calls.
+ */
+int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8, void* k8,
+                                      void* v8, float* scale_q, float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq,
+                                      int Skv, int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
+                                      void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * 16-bit sibling path: the non-fp8 build of the same kernel (TK_ATTN_IS_FP8 undefined, tk/attention.py:212,238-240,

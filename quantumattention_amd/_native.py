@@ -12,7 +12,7 @@ FMT_E4M3, FMT_E5M2, FMT_BF16, FMT_FP16 = 0, 1, 2, 3
 SCALE_HEAD, SCALE_TOKEN = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_KFRAG, LAYOUT_VFRAG, LAYOUT_K16FRAG, LAYOUT_V16FRAG = 0, 1, 2, 3, 4
 NUMERICS = {"compiled": 0, "eager": 1}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _FMT_OF_DTYPE = {
     torch.float8_e4m3fn: FMT_E4M3,
@@ -26,7 +26,7 @@ EXPORTS = (
     "qattn_abi_version", "qattn_strerror", "qattn_check_device", "qattn_fp8_tensor_bytes",
     "qattn_quant_workspace_bytes", "qattn_quant_fp8", "qattn_quant_qkv_workspace_bytes", "qattn_quant_qkv_fp8",
     "qattn_pack_fp8", "qattn_fp8_attention_forward",
-    "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16",
+    "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16", "qattn_fp8_quant_attention_forward",
 )
 
 _lib = None
@@ -68,6 +68,8 @@ def lib() -> ctypes.CDLL:
     L.qattn_pack16.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.qattn_attention_forward_16.restype = i
     L.qattn_attention_forward_16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
+    L.qattn_fp8_quant_attention_forward.restype = i
+    L.qattn_fp8_quant_attention_forward.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, vp, sz, vp]
     if L.qattn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libqattn_hip.so ABI {L.qattn_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = L
@@ -210,3 +212,32 @@ def attention_forward_16(q: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Te
                                           _stream(q))
     _check(rc, "qattn_attention_forward_16")
     return (out, lse) if return_lse else out
+
+
+def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, is_causal: bool, scaling: str = "head-wise",
+                                fp8_dtype=torch.float8_e4m3fn, numerics: str = "compiled", sm_scale: float = 0.0) -> torch.Tensor:
+    """16-bit q, k, v -> attention output: the quant pre-pass and the attention launch(es) in ONE C call
+    (qattn_fp8_quant_attention_forward); the pre-pass skips Q where the attention kernel quantises it itself."""
+    assert q.is_cuda and q.dim() == 4 and k.shape == v.shape and q.dtype == k.dtype == v.dtype
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, Hq, Sq, D = q.shape
+    _, Hkv, Skv, _ = k.shape
+    L = lib()
+    mode = SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
+    dev = q.device
+    with torch.cuda.device(dev):
+        out = torch.empty_like(q)
+        q8 = torch.empty((B, Hq, Sq, D), dtype=torch.uint8, device=dev)
+        kf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
+        vf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
+        sq = torch.empty((B, Hq) if mode == SCALE_HEAD else (B, Hq, Sq), dtype=torch.float32, device=dev)
+        sk = torch.empty((B, Hkv) if mode == SCALE_HEAD else (B, Hkv, Skv), dtype=torch.float32, device=dev)
+        sv = torch.empty((B, Hkv), dtype=torch.float32, device=dev)
+        ws_bytes = L.qattn_quant_qkv_workspace_bytes(B, Hq, Hkv)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        rc = L.qattn_fp8_quant_attention_forward(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
+            vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
+            NUMERICS[numerics], int(is_causal), float(sm_scale), ws.data_ptr(), ws_bytes, _stream(q))
+    _check(rc, "qattn_fp8_quant_attention_forward")
+    return out

@@ -35,12 +35,13 @@ static int kernel_variant() {
     return v;
 }
 
-extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, void* out, float* lse,
-                                           const float* scale_q, const float* scale_k, const float* scale_v, int B,
-                                           int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt,
-                                           int scale_mode, int is_causal, float sm_scale, void* stream) {
+// q16 != nullptr: the fused step -- Q is the bf16 tensor, quantised inside the kernel from q_amax_bits; scale_q is an OUTPUT.
+static int attention_impl(const void* q8, const void* k8, const void* v8, void* out, float* lse, const float* scale_q,
+                          const float* scale_k, const float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt,
+                          int v_fmt, int out_fmt, int scale_mode, int is_causal, float sm_scale, const void* q16,
+                          const unsigned* q_amax_bits, float* sq_out, int q_numerics, void* stream) {
     // argument checks mirror the reference launcher's TORCH_CHECKs (tk/attention.py:362-415)
-    if (!q8 || !k8 || !v8 || !out || !scale_q || !scale_k) return QATTN_ERR_INVALID_ARG;
+    if ((!q8 && !q16) || !k8 || !v8 || !out || (!scale_q && !q16) || !scale_k) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;  // nn.py:45-49
     if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;                    // tk/attention.py:398-399
@@ -73,6 +74,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     p.sm_log2e = sm * 1.4426950408889634f;
     p.exact_exp = exact_exp();
     p.use_v4 = kernel_variant() == 4 ? 1 : 0;
+    p.q16 = (const unsigned char*)q16; p.q_amax_bits = q_amax_bits; p.sq_out = sq_out; p.q_numerics = q_numerics;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (use_v4_full) rc = launch_attn_v4_full(p, D, qk_fmt, is_causal, scale_mode, st);
@@ -130,4 +132,43 @@ extern "C" int qattn_check_device(void) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return QATTN_ERR_DEVICE;
     return strstr(prop.gcnArchName, "gfx950") ? QATTN_OK : QATTN_ERR_DEVICE;
+}
+
+extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, void* out, float* lse,
+                                           const float* scale_q, const float* scale_k, const float* scale_v, int B,
+                                           int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt,
+                                           int scale_mode, int is_causal, float sm_scale, void* stream) {
+    return attention_impl(q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt,
+                          scale_mode, is_causal, sm_scale, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// true when the attention kernel can quantise Q itself (hand-scheduled D = 128 kernel, 8 waves, head-wise scales, bf16
+// inputs, byte-exponential path): then the pre-pass skips Q's payload (one read and one write of Q less).
+static bool q_fusion_ok(int D, int in_fmt, int scale_mode) {
+    return D == 128 && in_fmt == QATTN_FMT_BF16 && scale_mode == QATTN_SCALE_HEAD && kernel_variant() == 2 && !exact_exp() &&
+           env_int("QATTN_V2_WAVES", 8) == 8 && env_int("QATTN_NO_Q_FUSION", 0) == 0;
+}
+
+extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
+                                                 void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v, int B,
+                                                 int Hq, int Hkv, int Sq, int Skv, int D, int fp8_fmt, int scale_mode,
+                                                 int numerics, int is_causal, float sm_scale, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+    if (!q || !k || !v || !out || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
+    if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (fp8_fmt != QATTN_FMT_E4M3 && fp8_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (!workspace || workspace_bytes < qattn_quant_qkv_workspace_bytes(B, Hq, Hkv)) return QATTN_ERR_WORKSPACE;
+    const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode);
+    unsigned* ws = (unsigned*)workspace;
+    int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
+                              numerics, ws, fuse_q, (hipStream_t)stream);
+    if (rc != QATTN_OK) return rc;
+    return attention_impl(fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv,
+                          D, fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, fuse_q ? q : nullptr, fuse_q ? ws : nullptr,
+                          fuse_q ? scale_q : nullptr, numerics, stream);
 }

@@ -35,6 +35,10 @@ struct AttnParams {
     int lds_pad;     // development: force this dynamic-LDS size (occupancy experiments), 0 = natural
     unsigned long long* dbg_buf;  // development: per-wave {cycles, realtime ticks} of the KV sweep when dbg & 16
     int dbg;         // development: 16 = stamp per-wave sweep cycles into dbg_buf
+    const unsigned char* q16;      // fused step: the 16-bit (bf16) Q tensor, quantised row by row in the kernel prologue (else nullptr)
+    const unsigned* q_amax_bits;   // fused step: per-(b,h) abs-max bits of Q from the amax pass
+    float* sq_out;                 // fused step: scale_q [B,Hq] is written by the attention kernel
+    int q_numerics;
     int use_v4;      // 1: head-wise one-term byte-exponential q-blocks run on the three-waves-per-SIMD kernel (qattn_attn_v4.hip)
 };
 

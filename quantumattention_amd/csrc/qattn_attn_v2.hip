@@ -511,7 +511,10 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
 }
 
 // QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0>
+// Q16: the fused step (qattn_fp8_quant_attention_forward): Q arrives as bf16 and is quantised here, row by row, with the
+// same quant8 sequence as the pre-pass (bit-identical q8), from the head's abs-max bits -- the pre-pass then neither
+// re-reads Q nor writes q8, and this kernel reads 2 instead of 1 byte per Q element once.
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool Q16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p, const int qb_lo, const int qb_n) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
@@ -548,7 +551,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     // only the writing lane ever reads them back, so no barrier is needed (the compiler orders the lane's own
     // ds_write -> ds_read with lgkmcnt).
     unsigned char* qbuf = smem + kStagesV2 * STAGE + wave * (KS << 11) + (hh << 10) + (ql << 4);
-    {
+    float scale_q16 = 1.0f;
+    if (Q16) {
+        static_assert(!Q16 || !TOKEN, "the fused Q path is head-wise");
+        const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
+        scale_q16 = make_scale(__uint_as_float(p.q_amax_bits[(long)b * p.Hq + h]), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        if (q0_wg == 0 && tid == 0) p.sq_out[(long)b * p.Hq + h] = scale_q16;
+        const float rinv = 1.0f / scale_q16;
+        const bool qvalid = qrow < p.Sq;
+        const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            int2 w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint4 raw = qp[s * 8 + i];   // 8 elements each; the lane's 32 elements d = 64s + 32hh .. +31
+                if (!qvalid) raw = make_uint4(0, 0, 0, 0);
+                w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw, scale_q16, rinv);
+            }
+            *reinterpret_cast<v4i*>(qbuf + (s << 11)) = v4i{w[0].x, w[0].y, w[1].x, w[1].y};
+            *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = v4i{w[2].x, w[2].y, w[3].x, w[3].y};
+        }
+    } else {
         const bool qvalid = qrow < p.Sq;
         const unsigned char* qp = p.q + (((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32;
 #pragma unroll
@@ -563,6 +587,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210)
     float c;
     if (TOKEN) c = p.sm_log2e * (qrow < p.Sq ? p.sq[((long)b * p.Hq + h) * p.Sq + qrow] : 1.0f);
+    else if (Q16) c = p.sm_log2e * scale_q16 * p.sk[kv_head];
     else c = p.sm_log2e * p.sq[(long)b * p.Hq + h] * p.sk[kv_head];
     const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
 
@@ -645,13 +670,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     }
 }
 
-template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE>
+template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, bool Q16 = false>
 static int launch_attn_v2_one(const AttnParams& p, int qb_lo, int qb_n, hipStream_t st) {
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
     size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D;  // K/V ring + parked Q^T fragments
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
-    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, TWO, BYTE>;
+    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, TWO, BYTE, 0, Q16>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n);
     return QATTN_OK;
@@ -691,6 +716,10 @@ static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st)
         if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, true>(p, n_two, p.nqb - n_two, st);
         else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, false>(p, n_two, p.nqb - n_two, st);
         if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, true, false>(p, 0, n_two, st);
+    } else if (p.q16 != nullptr) {
+        // fused step: the API only takes this route for NW == 8, byte-exponential, head-wise (qattn_api.hip)
+        rc = launch_attn_v2_one<D, 8, FMT, CAUSAL, false, false, true, true>(p, n_two, p.nqb - n_two, st);
+        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, 8, FMT, CAUSAL, false, true, false, true>(p, 0, n_two, st);
     } else {
         if (byte_exp && p.use_v4 && D == 128) rc = launch_attn_v4(p, 128, FMT, CAUSAL, scale_mode, n_two * NW * kQPerWave, st);
         else if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, true>(p, n_two, p.nqb - n_two, st);

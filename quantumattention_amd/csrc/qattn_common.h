@@ -81,6 +81,19 @@ __device__ inline int cvt4_fp8(float a, float b, float c, float d) {
 // those vectors fall back to the exact sequence.  Requires a finite scale, which implies finite inputs (the scale is
 // derived from the group's abs-max).  Results below the fp8 subnormal range round to (signed) zero either way.
 // ---------------------------------------------------------------------------------------------------------
+// scale = clamp_min(amax * (1/fmax), eps_f32)   (nn.py:14-16; eager numerics round the scale and eps to the input dtype)
+__device__ inline float make_scale(float amax, float inv_qmax, int numerics, int in_fmt) {
+    const float eps = 1.1920928955078125e-07f;  // torch.finfo(torch.float32).eps  (nn.py:15)
+    float s = amax * inv_qmax;
+    float e = eps;
+    if (numerics == QATTN_NUMERICS_EAGER) {
+        s = in_fmt == QATTN_FMT_BF16 ? round_bf16(s) : round_fp16(s);
+        e = in_fmt == QATTN_FMT_BF16 ? round_bf16(eps) : round_fp16(eps);
+    }
+    if (!(s >= e)) s = (s != s) ? s : e;  // clamp_min keeps NaN
+    return s;
+}
+
 template <int IN_FMT, int OUT_FMT>
 __device__ __attribute__((noinline)) int2 quant8_exact_call(const uint4 raw, float scale);
 
@@ -133,5 +146,12 @@ __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv
     }
     return make_int2(cvt4_fp8<OUT_FMT>(c[0], c[1], c[2], c[3]), cvt4_fp8<OUT_FMT>(c[4], c[5], c[6], c[7]));
 }
+
+// q/k/v pre-pass launcher shared by qattn_quant_qkv_fp8 and the fused step entry (qattn_api.hip).  `ws` holds the amax bits
+// of q [B*Hq], k [B*Hkv], v [B*Hkv] (zeroed here).  skip_q_payload: q8 / scale_q are not written (the attention kernel
+// quantises its own Q rows from the 16-bit tensor and the q amax bits).
+int launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
+                     float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt, int scale_mode,
+                     int numerics, unsigned* ws, bool skip_q_payload, hipStream_t st);
 
 }  // namespace qattn

@@ -47,17 +47,6 @@ __global__ __launch_bounds__(256) void amax_kernel(const uint4* __restrict__ x, 
     }
 }
 
-__device__ inline float make_scale(float amax, float inv_qmax, int numerics, int in_fmt) {
-    const float eps = 1.1920928955078125e-07f;  // torch.finfo(torch.float32).eps  (nn.py:15)
-    float s = amax * inv_qmax;
-    float e = eps;
-    if (numerics == QATTN_NUMERICS_EAGER) {
-        s = in_fmt == QATTN_FMT_BF16 ? round_bf16(s) : round_fp16(s);
-        e = in_fmt == QATTN_FMT_BF16 ? round_bf16(eps) : round_fp16(eps);
-    }
-    if (!(s >= e)) s = (s != s) ? s : e;  // clamp_min keeps NaN
-    return s;
-}
 
 // Transposing copy-out of one staged fp8 tile (64 keys, row-major with VSTRIDE-byte rows in LDS) into its VFRAG chunk.
 // A thread owns 8 keys (the two 4-key groups w = 2wh, 2wh+1 of one (half, hh)) x 4 consecutive d: 8 conflict-free
@@ -459,8 +448,14 @@ extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, 
     if (out_fmt != QATTN_FMT_E4M3 && out_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
     const size_t need = qattn_quant_qkv_workspace_bytes(B, Hq, Hkv);
     if (!workspace || workspace_bytes < need) return QATTN_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned* ws = (unsigned*)workspace;
+    return qattn::launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, out_fmt, scale_mode,
+                                   numerics, (unsigned*)workspace, false, (hipStream_t)stream);
+}
+
+int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
+                            float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt,
+                            int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, hipStream_t st) {
+    const size_t need = qattn_quant_qkv_workspace_bytes(B, Hq, Hkv);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return QATTN_ERR_LAUNCH;
     const int tok = scale_mode == QATTN_SCALE_TOKEN;
     QuantJobs jobs;
@@ -480,7 +475,8 @@ extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, 
         if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, splits, 0);
         else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, splits, 0);
     }
-    dim3 grid((Smax + 63) / 64, Gmax, 3);
+    // the quantise pass walks jobs ztop, ztop-1, ...: with skip_q_payload only v and k (blockIdx.z = 0, 1)
+    dim3 grid(((skip_q_payload ? Skv : Smax) + 63) / 64, skip_q_payload ? B * Hkv : Gmax, skip_q_payload ? 2 : 3);
     int rc;
     if (D == 64) rc = launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, grid, 2, st);
     else if (D == 128) rc = launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, grid, 2, st);

@@ -107,12 +107,9 @@ def fp8_quant_attention_forward(
     """Fused entry for 16-bit inputs: the quant pre-pass (nn.py:410-418) writes K and V straight into the MFMA
     fragment layouts, then the attention kernel runs -- what `_fp8_attention_wrapper` (nn.py:394-430) does in the
     reference through Inductor, without the intermediate row-major K copy."""
-    fp8_dtype = _native.FP8_DTYPE[fp8_format]
-    q8, k_frag, v_frag, sq, sk, sv = _native.quant_qkv_fp8(query, key, value, scaling=scaling_method,
-                                                           fp8_dtype=fp8_dtype, numerics=numerics)
-    return _native.fp8_attention_forward(
-        q8, k_frag, v_frag, sq, sk, sv, Hkv=key.shape[1], Skv=key.shape[2], out_dtype=value.dtype,
-        is_causal=is_causal, scaling=scaling_method, sm_scale=0.0 if scale is None else float(scale))
+    return _native.fp8_quant_attention_forward(
+        query, key, value, is_causal=is_causal, scaling=scaling_method, fp8_dtype=_native.FP8_DTYPE[fp8_format],
+        numerics=numerics, sm_scale=0.0 if scale is None else float(scale))
 
 
 @_register_fake("quantumattention_amd::fp8_quant_attention_forward")
