@@ -370,10 +370,10 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
 }
 
 // The KV sweep of one wave.  Returns with st.o / st.l_run / st.m_run final.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, typename LoadQ>
 __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
-                                         int n_w, int q0, int qrow, int wave, int lane, const float* skt) {
+                                         int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q) {
     constexpr int CH = 64 * D, STAGE = 2 * CH;
     const int hh = lane >> 5;
     const int T = n_wg + 2;  // iterations t = 0 .. n_wg+1 : QK(t), softmax(t-1), PV(t-2)
@@ -416,6 +416,7 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
 #pragma unroll
     for (int g = 0; g < kSyncEvery; g++)
         if (g < T) dma_for(g);
+    load_q();  // the wave's Q^T rows (global -> [quantise ->] LDS / registers) travel while the first K/V stages do
     unsigned slot_cur = 0, slot_prev = 0;
     auto sync_iter = [&](int t, bool in_step = false) -> const unsigned char* {
         (void)in_step;
@@ -557,32 +558,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
         scale_q16 = make_scale(__uint_as_float(p.q_amax_bits[(long)b * p.Hq + h]), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         if (q0_wg == 0 && tid == 0) p.sq_out[(long)b * p.Hq + h] = scale_q16;
-        const float rinv = 1.0f / scale_q16;
-        const bool qvalid = qrow < p.Sq;
-        const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-            int2 w[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint4 raw = qp[s * 8 + i];   // 8 elements each; the lane's 32 elements d = 64s + 32hh .. +31
-                if (!qvalid) raw = make_uint4(0, 0, 0, 0);
-                w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw, scale_q16, rinv);
-            }
-            *reinterpret_cast<v4i*>(qbuf + (s << 11)) = v4i{w[0].x, w[0].y, w[1].x, w[1].y};
-            *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = v4i{w[2].x, w[2].y, w[3].x, w[3].y};
-        }
-    } else {
-        const bool qvalid = qrow < p.Sq;
-        const unsigned char* qp = p.q + (((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32;
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-            v4i lo = *reinterpret_cast<const v4i*>(qp + s * 64);
-            v4i hi = *reinterpret_cast<const v4i*>(qp + s * 64 + 16);
-            if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
-            *reinterpret_cast<v4i*>(qbuf + (s << 11)) = lo;
-            *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = hi;
-        }
     }
     // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210)
     float c;
@@ -604,11 +579,45 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr bool QREG = BYTE && !TWO && !(ABL & 128);  // one-term byte kernel: 16 registers to spare for the Q^T fragments
-    if (QREG) {
-        st.qreg[0] = lds_read_frag(qbuf);
-        st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
-    }
-    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt);
+    // invoked by kv_sweep right after the first K/V stages have been requested, so the two latencies overlap
+    auto load_q = [&]() {
+        const bool qvalid = qrow < p.Sq;
+        if (Q16) {
+            const float rinv = 1.0f / scale_q16;
+            const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
+            uint4 raw[KS][4];
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    raw[s][i] = qp[s * 8 + i];   // 8 elements each; the lane's 32 elements d = 64s + 32hh .. +31
+                    if (!qvalid) raw[s][i] = make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                int2 w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw[s][i], scale_q16, rinv);
+                *reinterpret_cast<v4i*>(qbuf + (s << 11)) = v4i{w[0].x, w[0].y, w[1].x, w[1].y};
+                *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = v4i{w[2].x, w[2].y, w[3].x, w[3].y};
+            }
+        } else {
+            const unsigned char* qp = p.q + (((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                v4i lo = *reinterpret_cast<const v4i*>(qp + s * 64);
+                v4i hi = *reinterpret_cast<const v4i*>(qp + s * 64 + 16);
+                if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
+                *reinterpret_cast<v4i*>(qbuf + (s << 11)) = lo;
+                *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = hi;
+            }
+        }
+        if (QREG) {
+            st.qreg[0] = lds_read_frag(qbuf);
+            st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
+        }
+    };
+    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q);
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
