@@ -86,6 +86,7 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    os.environ.setdefault("QATTN_STEP_EVENTS", "1")  # the library brackets attention launches with HIP events (bench only)
     import quantumattention_amd as qa
     from quantumattention_amd import _native
 
@@ -139,22 +140,23 @@ def main():
         return e0.elapsed_time(e1) / n  # ms per launch
 
     def attn_in_step(n):
-        """The attention kernel's launch duration INSIDE the step sequence (pre-pass -> attention, back to back, K times):
-        HIP events on the launch stream right before / after the attention launch of every step."""
+        """The attention launch's duration INSIDE the real step (the fused C entry: pre-pass -> attention), from the two HIP
+        events the library records on the launch stream around the attention launch (QATTN_STEP_EVENTS=1)."""
         for _ in range(3):
-            quant_only(); attn_only()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        torch.cuda.synchronize()
-        for e0, e1 in ev:
-            pack = _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype)
-            e0.record()
-            _native.fp8_attention_forward(*pack, Hkv=H, Skv=S, out_dtype=torch.bfloat16, is_causal=args.causal)
-            e1.record()
-        torch.cuda.synchronize()
-        return sum(e0.elapsed_time(e1) for e0, e1 in ev) / n
+            step()
+        tot = 0.0
+        for _ in range(n):
+            step()
+            ms = _native.lib().qattn_debug_last_attention_ms()   # waits for this step's attention to finish
+            if ms < 0:
+                return None
+            tot += ms
+        return tot / n
 
-    attn_ms = attn_in_step(args.steps)             # what the roofline is computed from
-    attn_isolated_ms = event_time(attn_only, args.steps)   # the same kernel launched back to back (warm caches)
+    attn_isolated_ms = event_time(attn_only, args.steps)   # the kernel launched back to back on pre-quantised operands
+    attn_ms = attn_in_step(args.steps)                     # what the roofline is computed from: the launch inside the step
+    if attn_ms is None:
+        attn_ms = attn_isolated_ms
     quant_ms = event_time(quant_only, args.steps)
     # informational: the same step replayed from a HIP graph (no launch gaps); `value` stays the eager API call
     graph_ms = None
@@ -185,7 +187,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collectives"},
             "frac_of_fp8_mfma_peak": value / (FP8_PEAK_TFLOPS * world),
             "attn_kernel_ms": attn_ms, "attn_kernel_isolated_ms": attn_isolated_ms, "quant_prepass_ms": quant_ms, "graph_replay_ms_per_step": graph_ms,
-            "roofline": {"kernel": "qattn::attn_fwd_kernel_v2<128,8,e4m3,e4m3,...> (fused QK^T/softmax/PV)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "qattn::attn_fwd_kernel_v2<128,8,e4m3,e4m3,...,Q16> (fused QK^T/softmax/PV; timed inside the step)", "bound": "mfma", "achieved": achieved,
                          "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP8_PEAK_TFLOPS,
                          "traffic": traffic},
         }

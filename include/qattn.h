@@ -160,6 +160,11 @@ int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H, int S, in
 int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, void* out, float* lse, int B, int Hq,
                                int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, void* stream);
 
+/* Development aid (not part of the drop-in surface): with QATTN_STEP_EVENTS=1 in the environment every attention launch is
+ * bracketed by two HIP events on its stream; this returns the milliseconds between them for the most recent launch
+ * (synchronises on the second event), or a negative value when disabled. */
+float qattn_debug_last_attention_ms(void);
+
 #ifdef __cplusplus
 }
 #endif

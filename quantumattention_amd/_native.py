@@ -27,6 +27,7 @@ EXPORTS = (
     "qattn_quant_workspace_bytes", "qattn_quant_fp8", "qattn_quant_qkv_workspace_bytes", "qattn_quant_qkv_fp8",
     "qattn_pack_fp8", "qattn_fp8_attention_forward",
     "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16", "qattn_fp8_quant_attention_forward",
+    "qattn_debug_last_attention_ms",
 )
 
 _lib = None
@@ -68,6 +69,7 @@ def lib() -> ctypes.CDLL:
     L.qattn_pack16.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.qattn_attention_forward_16.restype = i
     L.qattn_attention_forward_16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
+    L.qattn_debug_last_attention_ms.restype = ctypes.c_float
     L.qattn_fp8_quant_attention_forward.restype = i
     L.qattn_fp8_quant_attention_forward.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, vp, sz, vp]
     if L.qattn_abi_version() != ABI_VERSION:

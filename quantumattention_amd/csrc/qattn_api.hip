@@ -35,6 +35,18 @@ static int kernel_variant() {
     return v;
 }
 
+static hipEvent_t g_ev[2] = {nullptr, nullptr};
+
+// development (QATTN_STEP_EVENTS=1): milliseconds between the HIP events recorded right before and right after the most
+// recent attention launch(es) on their stream; synchronises on the second event.  Used by bench.py to time the attention
+// kernel inside the fused step without a profiler.
+extern "C" float qattn_debug_last_attention_ms(void) {
+    if (!g_ev[0]) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(g_ev[1]) != hipSuccess || hipEventElapsedTime(&ms, g_ev[0], g_ev[1]) != hipSuccess) return -1.0f;
+    return ms;
+}
+
 // q16 != nullptr: the fused step -- Q is the bf16 tensor, quantised inside the kernel from q_amax_bits; scale_q is an OUTPUT.
 static int attention_impl(const void* q8, const void* k8, const void* v8, void* out, float* lse, const float* scale_q,
                           const float* scale_k, const float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt,
@@ -76,10 +88,16 @@ static int attention_impl(const void* q8, const void* k8, const void* v8, void* 
     p.use_v4 = kernel_variant() == 4 ? 1 : 0;
     p.q16 = (const unsigned char*)q16; p.q_amax_bits = q_amax_bits; p.sq_out = sq_out; p.q_numerics = q_numerics;
     hipStream_t st = (hipStream_t)stream;
+    static const bool step_events = env_int("QATTN_STEP_EVENTS", 0) != 0;  // development: time this launch inside a longer sequence
+    if (step_events) {
+        if (!g_ev[0]) { (void)hipEventCreate(&g_ev[0]); (void)hipEventCreate(&g_ev[1]); }
+        (void)hipEventRecord(g_ev[0], st);
+    }
     int rc;
     if (use_v4_full) rc = launch_attn_v4_full(p, D, qk_fmt, is_causal, scale_mode, st);
     else if (use_v3) rc = launch_attn_v3(p, D, qk_fmt, is_causal, scale_mode, st);
     else rc = launch_attn_v2(p, D, qk_fmt, is_causal, scale_mode, st);
+    if (step_events) (void)hipEventRecord(g_ev[1], st);
     if (rc != QATTN_OK) return rc;
     if ((p.dbg & 16) && p.dbg_buf) {  // diagnostic build path only: synchronises and prints per-wave sweep statistics
         static int printed = 0;

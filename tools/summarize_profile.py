@@ -37,8 +37,11 @@ with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 
 attn = [k for k in summary if "attn_fwd_kernel" in k]
+# the in-step instantiation (last template argument Q16 = true: it reads Q as bf16) when present, else the plain one
+fused = [k for k in attn if k.rstrip().rstrip(">").rstrip().endswith("true")]
 if attn:
-    s = summary[attn[0]]
+    key = fused[0] if fused else attn[0]
+    s = summary[key]
     # FETCH_SIZE / WRITE_SIZE count 64-byte... units of 1 KiB per the guide's rocprofv3 section; FETCH_SIZE under-reports by 2x on gfx950
     fetch = s["FETCH_SIZE"] * 1024 * 2
     write = s["WRITE_SIZE"] * 1024
@@ -48,7 +51,8 @@ if attn:
         "fetch_bytes_x2_corrected": fetch,
         "write_bytes": write,
         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; %s/pmc_summary.json" % dst,
-        "algorithmic_bytes": B * H * S * D * (3 + 2),
+        "algorithmic_bytes": B * H * S * D * ((2 + 1 + 1 + 2) if fused else (3 + 2)),  # Q (bf16 or fp8) + K + V fp8 + O bf16
+        "kernel": key,
     }
     with open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
