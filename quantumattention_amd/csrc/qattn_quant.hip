@@ -464,7 +464,10 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
     jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + (size_t)B * (Hq + Hkv), B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0};
     // (Tried and dropped: one tensor at a time -- amax then quantise, hoping the re-read hits the 256 MiB Infinity Cache --
     // was 13 % slower than the two fused launches; a one-pass register-resident variant with a cross-workgroup amax
-    // exchange was 2-6x slower, the agent-scope atomics + spinning cost more than the second read.)
+    // exchange was 2-6x slower, the agent-scope atomics + spinning cost more than the second read.  A third variant --
+    // all slices of a head pinned to ONE XCD, abs-max exchanged through that XCD's L2, slice re-read instead of held in
+    // registers -- measured 0.42 ms vs 0.18: the exchange alone costs 0.2 ms and the re-read is NOT served on-die even with
+    // residency capped to 2 workgroups per CU (amax only 0.071 ms, amax + re-read without any exchange 0.19 ms).)
     const int Gmax = B * (Hq > Hkv ? Hq : Hkv), Smax = Sq > Skv ? Sq : Skv;
     {
         const long vecs = (long)Smax * D / 8;
