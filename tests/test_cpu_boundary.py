@@ -104,3 +104,26 @@ def test_native_binding_fails_loudly_without_the_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "missing.so"))
     with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
         _native.lib()
+
+
+def test_fake_impls_of_every_custom_op_without_a_gpu():
+    """register_fake coverage: under FakeTensorMode every op of the boundary returns the documented
+    shape / dtype / device for fake "cuda" tensors -- what torch.compile sees when it traces a caller (ops.py:45, 121)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from quantumattention_amd import ops  # noqa: F401  (registers the ops)
+
+    with FakeTensorMode():
+        q = torch.empty(2, 8, 300, 128, dtype=torch.bfloat16, device="cuda")
+        k = torch.empty(2, 2, 512, 128, dtype=torch.bfloat16, device="cuda")
+        v = torch.empty(2, 2, 512, 128, dtype=torch.float16, device="cuda")
+        o = torch.ops.quantumattention_amd.fp8_quant_attention_forward(q, k, v.bfloat16(), True, "token-wise", "e5m2")
+        assert o.shape == q.shape and o.dtype == torch.bfloat16 and o.device.type == "cuda"
+        q8, sq = torch.ops.quantumattention_amd.dynamically_quantize_fp8(q, False, "e4m3", "compiled")
+        k8, sk = torch.ops.quantumattention_amd.dynamically_quantize_fp8(k, True, "e5m2", "eager")
+        assert q8.dtype == torch.float8_e4m3fn and q8.shape == q.shape and sq.shape == (2, 8) and sq.dtype == torch.float32
+        assert k8.dtype == torch.float8_e5m2 and sk.shape == (2, 2, 512)
+        o = torch.ops.quantumattention_amd.fp8_attention_forward(q8, q8[:, :2], v[:, :, :300], sq, sq[:, :2], None, 0.0, False)
+        assert o.shape == q.shape and o.dtype == torch.float16   # output takes value's dtype (tk/attention.py:434-437)
+        o = torch.ops.quantumattention_amd.attention_forward(q, q, q, None, 0.0, True)
+        assert o.shape == q.shape and o.dtype == torch.bfloat16
