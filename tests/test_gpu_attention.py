@@ -199,6 +199,37 @@ def test_full_size_properties_B4_H32_S4096_D128(causal):
         assert (outp.float() - out[:1].float()).abs().max() < TOL
 
 
+def test_full_size_properties_config5_shape_S16384_H40_e5m2_causal():
+    """BASELINE config 5's shape and format (float8_e5m2, causal, S = 16384, 40 heads, B = 1) at full size."""
+    torch.manual_seed(5)
+    B, H, S, D = 1, 40, 16384, 128
+    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    with qa.config.patch({"attention.fp8_format": "e5m2"}):
+        out = qa.fp8_attn_func(q, k, v, is_causal=True)
+        assert torch.isfinite(out).all()
+        assert torch.equal(out, qa.fp8_attn_func(q, k, v, is_causal=True))                           # determinism
+        assert torch.equal(out[:, 8:16], qa.fp8_attn_func(q[:, 8:16], k[:, 8:16], v[:, 8:16], is_causal=True))  # head-shard equivalence
+        assert torch.equal(qa.fp8_attn_func(q[:, :8], k[:, :8], v[:, :8] * 2, is_causal=True), out[:, :8] * 2)  # exact V-linearity
+    # oracle on one head: the first 1.5 k rows (two-term rows and the switch to the byte path) and the last 256 rows
+    h = 17
+    qs, ks, vs = q[:, h:h + 1].cpu(), k[:, h:h + 1].cpu(), v[:, h:h + 1].cpu()
+    q8, sq = oracle.quantize_fp8(bits16(qs), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
+    k8, sk = oracle.quantize_fp8(bits16(ks), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
+    top = 1536   # top-left causal alignment: query rows [0, top) against the full K / V (V quantised with the head's scale)
+    ref_top = oracle_for_fp8_path(q8[:, :, :top], k8, bits16(vs), sq, sk, fp8="e5m2", causal=True)
+    mx, rmse = err_stats(out_to_f32(out[0, h, :top]), ref_top[0, 0])
+    assert mx < tol_for(ref_top) and rmse < 3e-3, (mx, rmse)
+    # last rows see every key: non-causal oracle rows == causal rows for the final row only; use Sq != Skv non-causal instead
+    tail = slice(S - 256, S)
+    ref_tail = oracle_for_fp8_path(q8[:, :, tail], k8, bits16(vs), sq, sk, fp8="e5m2", causal=False)
+    with qa.config.patch({"attention.fp8_format": "e5m2"}):
+        out_tail = torch.ops.quantumattention_amd.fp8_attention_forward(
+            torch.from_numpy(q8[:, :, tail].copy()).view(torch.float8_e5m2).cuda(), torch.from_numpy(k8).view(torch.float8_e5m2).cuda(),
+            v[:, h:h + 1], torch.from_numpy(sq).cuda(), torch.from_numpy(sk).cuda(), None, 0.0, False)
+    mx, rmse = err_stats(out_to_f32(out_tail[0, 0]), ref_tail[0, 0])
+    assert mx < TOL, (mx, rmse)
+
+
 def test_hip_graph_capture_of_the_whole_step():
     """The C ABI promises "no host synchronisation, no allocation, graph-capture safe" (include/qattn.h): capture
     quant pre-pass + attention (and the 16-bit path) in a HIP graph, replay it on new input data, compare bit-exactly
