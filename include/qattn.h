@@ -153,7 +153,7 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
  * 289-313) behind `quantum_attn::attention_forward(query, key, value, scale=None, is_causal=False)`
  * (src/quantum_attn/ops.py:17-45).  q/out row-major [B,Hq,Sq,D] bf16 or fp16 (`fmt`); k16/v16 are the key/value
  * tensors re-laid by qattn_pack16 into QATTN_LAYOUT_K16FRAG / QATTN_LAYOUT_V16FRAG (qattn_16bit_tensor_bytes bytes).
- * D in {64,128}.  Both GEMMs run on v_mfma_f32_32x32x16_{bf16,f16}; softmax, running max/sum and accumulation fp32.
+ * D in {64,128,256}.  Both GEMMs run on v_mfma_f32_32x32x16_{bf16,f16}; softmax, running max/sum and accumulation fp32.
  */
 size_t qattn_16bit_tensor_bytes(int layout, int B, int H, int S, int D);
 int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H, int S, int D, int out_layout, void* stream);

@@ -66,7 +66,7 @@ constexpr int kStages16 = 2;
 constexpr float kFastExpBias = -0.0575f;  // centres the (1+f)/2^f mantissa error
 
 template <int D, int FMT16, bool CAUSAL, bool FAST>
-__global__ __launch_bounds__(kWaves16 * 64, 3) void attn16_fwd_kernel(const Attn16Params p, const int qb_lo, const int qb_n) {
+__global__ __launch_bounds__(kWaves16 * 64, (D == 256 ? 2 : 3)) void attn16_fwd_kernel(const Attn16Params p, const int qb_lo, const int qb_n) {
     typedef typename T16<FMT16>::vec vec16;
     typedef typename T16<FMT16>::elt elt16;
     constexpr int TB = 32 * D * 2;       // bytes of one 32-key K (or V) tile
@@ -159,18 +159,23 @@ __global__ __launch_bounds__(kWaves16 * 64, 3) void attn16_fwd_kernel(const Attn
         for (int r = 0; r < 16; r++) sc[r] = 0.0f;
         // all K fragments of the tile are requested before the MFMA chain starts (left alone the compiler re-uses one
         // register quad and waits for every ds_read right before the MFMA that consumes it)
-        vec16 ka[KS];
+        // (D = 256: in batches of four, O^T and Q^T alone hold 192 registers)
+        constexpr int KB = KS > 8 ? 4 : KS;
 #pragma unroll
-        for (int s = 0; s < KS; s++) ka[s] = *reinterpret_cast<const vec16*>(kbuf + (s << 10));
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s0 = 0; s0 < KS; s0 += KB) {
+            vec16 ka[KB];
 #pragma unroll
-        for (int s = 0; s < KS; s++) sc = T16<FMT16>::mfma(ka[s], qf[s], sc);
-        __builtin_amdgcn_sched_barrier(0);
-        // the first half of the V fragments travels while the softmax runs
-        constexpr int NV = 2 * MB, NV0 = NV < 4 ? NV : 4;
-        vec16 va[NV];
+            for (int s = 0; s < KB; s++) ka[s] = *reinterpret_cast<const vec16*>(kbuf + ((s0 + s) << 10));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NV0; i++) va[i] = *reinterpret_cast<const vec16*>(vbuf + (i << 10));
+            for (int s = 0; s < KB; s++) sc = T16<FMT16>::mfma(ka[s], qf[s0 + s], sc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the first batch of V fragments travels while the softmax runs
+        constexpr int NV = 2 * MB, VB = NV < 4 ? NV : 4;
+        vec16 va[VB];
+#pragma unroll
+        for (int i = 0; i < VB; i++) va[i] = *reinterpret_cast<const vec16*>(vbuf + (i << 10));
         __builtin_amdgcn_sched_barrier(0);
         const int k0 = t * 32;
         const bool need_mask = (k0 + 32 > p.Skv) || (CAUSAL && k0 + 31 > q0);
@@ -237,15 +242,23 @@ __global__ __launch_bounds__(kWaves16 * 64, 3) void attn16_fwd_kernel(const Attn
                 }
             l_run += ls;
         }
-        // ---- O^T += V^T.P^T (the second half of the V fragments lands under the first MFMAs)
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T += V^T.P^T, V fragments in batches of VB: batch b+1 is requested before batch b's MFMAs are issued
 #pragma unroll
-        for (int i = NV0; i < NV; i++) va[i] = *reinterpret_cast<const vec16*>(vbuf + (i << 10));
-        __builtin_amdgcn_sched_barrier(0);
+        for (int b0 = 0; b0 < NV; b0 += VB) {
+            vec16 vn[VB];
+            __builtin_amdgcn_sched_barrier(0);
+            if (b0 + VB < NV) {
 #pragma unroll
-        for (int m = 0; m < MB; m++)
+                for (int i = 0; i < VB; i++) vn[i] = *reinterpret_cast<const vec16*>(vbuf + ((b0 + VB + i) << 10));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; i++) o[m] = T16<FMT16>::mfma(va[m * 2 + i], pb[i], o[m]);
+            for (int i = 0; i < VB; i++) o[(b0 + i) >> 1] = T16<FMT16>::mfma(va[i], pb[(b0 + i) & 1], o[(b0 + i) >> 1]);
+            if (b0 + VB < NV) {
+#pragma unroll
+                for (int i = 0; i < VB; i++) va[i] = vn[i];
+            }
+        }
     }
 
     float l_tot;
@@ -323,6 +336,7 @@ static int launch16_one(const Attn16Params& p, int row_lo, int row_hi, hipStream
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
     const size_t lds = (size_t)kStages16 * 2 * 32 * D * 2;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attn16_fwd_kernel<D, FMT16, CAUSAL, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL((attn16_fwd_kernel<D, FMT16, CAUSAL, FAST>), dim3(grid), dim3(kWaves16 * 64), lds, st, p, qb_lo, qb_n);
     return QATTN_OK;
 }
@@ -356,15 +370,15 @@ extern "C" size_t qattn_16bit_tensor_bytes(int layout, int B, int H, int S, int 
 
 extern "C" int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H, int S, int D, int out_layout, void* stream) {
     if (!x_rowmajor || !x_packed || B <= 0 || H <= 0 || S <= 0) return QATTN_ERR_INVALID_ARG;
-    if (D != 64 && D != 128) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
     if (out_layout != QATTN_LAYOUT_K16FRAG && out_layout != QATTN_LAYOUT_V16FRAG) return QATTN_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((S + 63) / 64, B * H), block(256);
     const uint4* xi = (const uint4*)x_rowmajor;
     uint4* xo = (uint4*)x_packed;
 #define PK16(DD, LAY) hipLaunchKernelGGL((pack16_tile_kernel<DD, LAY>), grid, block, 0, st, xi, xo, S)
-    if (out_layout == QATTN_LAYOUT_K16FRAG) { if (D == 64) PK16(64, QATTN_LAYOUT_K16FRAG); else PK16(128, QATTN_LAYOUT_K16FRAG); }
-    else { if (D == 64) PK16(64, QATTN_LAYOUT_V16FRAG); else PK16(128, QATTN_LAYOUT_V16FRAG); }
+    if (out_layout == QATTN_LAYOUT_K16FRAG) { if (D == 64) PK16(64, QATTN_LAYOUT_K16FRAG); else if (D == 128) PK16(128, QATTN_LAYOUT_K16FRAG); else PK16(256, QATTN_LAYOUT_K16FRAG); }
+    else { if (D == 64) PK16(64, QATTN_LAYOUT_V16FRAG); else if (D == 128) PK16(128, QATTN_LAYOUT_V16FRAG); else PK16(256, QATTN_LAYOUT_V16FRAG); }
 #undef PK16
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
@@ -373,7 +387,7 @@ extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const 
                                           int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, void* stream) {
     if (!q || !k16 || !v16 || !out) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
-    if (D != 64 && D != 128) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
     if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
     if (fmt != QATTN_FMT_BF16 && fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
     Attn16Params p;
@@ -388,7 +402,8 @@ extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (D == 64) rc = fmt == QATTN_FMT_BF16 ? launch16<64, QATTN_FMT_BF16>(p, is_causal, st) : launch16<64, QATTN_FMT_FP16>(p, is_causal, st);
-    else rc = fmt == QATTN_FMT_BF16 ? launch16<128, QATTN_FMT_BF16>(p, is_causal, st) : launch16<128, QATTN_FMT_FP16>(p, is_causal, st);
+    else if (D == 128) rc = fmt == QATTN_FMT_BF16 ? launch16<128, QATTN_FMT_BF16>(p, is_causal, st) : launch16<128, QATTN_FMT_FP16>(p, is_causal, st);
+    else rc = fmt == QATTN_FMT_BF16 ? launch16<256, QATTN_FMT_BF16>(p, is_causal, st) : launch16<256, QATTN_FMT_FP16>(p, is_causal, st);
     if (rc != QATTN_OK) return rc;
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }

@@ -12,7 +12,7 @@ from . import config
 from .utils import checks
 
 _HIP_SUPPORTED_HEAD_DIMS = [64, 128, 256]  # nn.py:45
-_HIP_16BIT_HEAD_DIMS = [64, 128]  # the 16-bit kernel keeps O^T (D/32 x 16 fp32) + Q^T (D/4 dwords) in registers
+_HIP_16BIT_HEAD_DIMS = [64, 128, 256]  # same set as the fp8 path (nn.py:45)
 _FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
 
 

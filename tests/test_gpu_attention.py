@@ -302,7 +302,7 @@ def test_c_abi_error_codes_instead_of_exceptions():
                                                                               P(ws), ctypes.c_size_t(ws_bytes), None)
     assert quant(ws_bytes=4) == -4                                      # workspace too small (needs 2 heads x 4 bytes)
     assert quant(D=100) == -2 and quant(in_fmt=0) == -3 and quant(out_fmt=2) == -3
-    assert L.qattn_pack16(P(x), P(x8), 1, 2, 64, 256, 3, None) == -2    # the 16-bit path has D in {64,128}
+    assert L.qattn_pack16(P(x), P(x8), 1, 2, 64, 96, 3, None) == -2     # head_dim not in {64,128,256}
     assert L.qattn_attention_forward_16(P(x), P(x), P(x), P(out), None, 1, 2, 2, 64, 64, 128, 0, 0, f0, None) == -3
     torch.cuda.synchronize()
     for code in (0, -1, -2, -3, -4, -5, -6):

@@ -38,7 +38,7 @@ def unpack16(buf: np.ndarray, layout: int, B: int, H: int, S: int, D: int) -> np
     return x[..., off].reshape(B, H, Sp, D)
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("S", [64, 200, 1])
 def test_pack16_layouts_bit_exact(D, S):
     torch.manual_seed(1)
@@ -67,6 +67,9 @@ CASES = [
     (1, 1, 1, 3, 70, 64, False, torch.bfloat16),
     (3, 5, 5, 300, 300, 128, True, torch.bfloat16),       # B*H not a multiple of 8
     (1, 8, 8, 2048, 2048, 128, False, torch.bfloat16),
+    (1, 2, 2, 1100, 1100, 256, True, torch.bfloat16),     # D = 256: exact + fast launches, ragged
+    (1, 4, 2, 1500, 1200, 256, False, torch.float16),     # GQA, Sq != Skv
+    (2, 2, 2, 100, 100, 256, False, torch.bfloat16),
 ]
 
 
@@ -124,12 +127,12 @@ def test_attn_func_rejects_what_the_reference_rejects():
         qa.attn_func(q, q, q.half())
     with pytest.raises(ValueError):
         qa.attn_func(q.float(), q.float(), q.float())
-    q256 = torch.randn(1, 2, 128, 256, dtype=torch.bfloat16, device="cuda")
+    q96 = torch.randn(1, 2, 128, 96, dtype=torch.bfloat16, device="cuda")   # head_dim not in {64,128,256} (nn.py:45-49)
     with pytest.raises(ValueError):
-        qa.attn_func(q256, q256, q256)
+        qa.attn_func(q96, q96, q96)
     # ... and the with_fallback op routes the same input to aten SDPA instead (interface.py:62-98)
-    out = qa.attn_func_with_fallback(q256, q256, q256)
-    ref = torch.nn.functional.scaled_dot_product_attention(q256, q256, q256)
+    out = qa.attn_func_with_fallback(q96, q96, q96)
+    ref = torch.nn.functional.scaled_dot_product_attention(q96, q96, q96)
     assert torch.equal(out, ref)
 
 
