@@ -5,22 +5,29 @@ One "step" = one pass of the hot path over one batch: `fp8_attn_func(q, k, v)` o
 resident in HBM, i.e. the bf16->fp8 quant pre-pass of q, k, v AND the fused attention kernel (what the
 reference's own benchmark times, tests/test_interface.py:104-108,136).  Workload = BASELINE.json configs[1]:
 B=4 H=32 S=4096 D=128 non-causal e4m3 per GPU; with --gpus N every rank runs that shard (batch-sharded
-B = 4N, configs[3] at N=8; no collective on the data path -- SURVEY.md §8e), so scaling is "weak".
+B = 4N, configs[3] at N=8; no collective on the data path -- SURVEY.md section 8e), so scaling is "weak".
+
+`python bench.py --gpus N` launches its N ranks itself (one process per GPU, RCCL only for the barrier and the MAX
+reduction of the elapsed time); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it
+takes RANK / LOCAL_RANK / WORLD_SIZE from the environment instead.  `--dry-run` swaps the device step for a host
+stub and RCCL for gloo so that the launcher / sharding / reduction logic runs on a CPU-only box (tests).
 
 FLOPs follow the reference convention 4*B*H*Sq*Skv*D (tests/test_interface.py:121-125).
 The JSON line also carries
-  roofline     -- the dominant kernel (attn_fwd_kernel) alone: algorithmic FLOPs per launch / its average launch
-                  duration measured with HIP events on the launch stream, against the 5.0 PFLOP/s dense fp8 MFMA peak;
+  roofline     -- the dominant kernel (the fused attention kernel) alone: algorithmic FLOPs per launch / its average
+                  launch duration measured with HIP events on the launch stream INSIDE the step, against the 5.0 PFLOP/s
+                  dense fp8 MFMA peak;
   cpu_baseline -- the reference's CPU path (torch port of ops.py:64-95, oracle/torch_ref.py) timed on the host cores
-                  on a bounded sample of the same workload.
+                  on a bounded sample of the same workload;
+  sustained_ms_per_step, c3_*, c5_* -- a >= 2 s back-to-back run and the causal / long-context configs (N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,19 +35,22 @@ sys.path.insert(0, ROOT)
 FP8_PEAK_TFLOPS = 5000.0  # MI355X dense fp8 MFMA peak (MI355X_MICROARCH.md: ~5 PF dense)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=4, help="batch elements PER GPU")
     ap.add_argument("--heads", type=int, default=32)
     ap.add_argument("--seq", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--causal", action="store_true")
     ap.add_argument("--fp8", default="e4m3", choices=["e4m3", "e5m2"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "fast", "accurate"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the sustained run and the C3 / C5 configs")
+    ap.add_argument("--dry-run", action="store_true", help="host stub instead of the device step, gloo instead of RCCL")
+    return ap.parse_args(argv)
 
 
 def flops(B, H, Sq, Skv, D, causal):
@@ -48,8 +58,32 @@ def flops(B, H, Sq, Skv, D, causal):
     return f / 2 if causal else f
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """Parent of a multi-GPU run: start one child per GPU BEFORE anything here touches a GPU (a process that has initialised
+    HIP must not be replaced or forked), pass rank 0's JSON line through, return the worst exit code."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), QATTN_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def cpu_baseline(args, q, k, v):
     """Reference CPU path on a bounded sample: one batch element (H heads) of the same workload."""
+    import torch
     from oracle import torch_ref
 
     threads = os.cpu_count() or 1
@@ -72,131 +106,222 @@ def cpu_baseline(args, q, k, v):
     }
 
 
-def main():
-    args = parse()
+def kernel_label(D, fp8, causal, fused_q):
+    """The kernel the dispatch in qattn_api.hip / qattn_attn_v2.hip / qattn_attn_v4.hip selects for a head-wise call."""
+    if D == 128:
+        return (f"qattn::attn_fwd_kernel_v2<D=128, 8 waves, {fp8}, {'causal' if causal else 'full'}, head-wise, byte-exp"
+                f"{', Q quantised in-kernel' if fused_q else ''}> (fused QK^T / softmax / PV; one launch per batch group, all query blocks)")
+    return f"qattn::attn_fwd_kernel_v4<D={D}, {fp8}, {'causal' if causal else 'full'}, head-wise, byte-exp> (+ two-term launch for early causal rows)"
+
+
+def run_rank(args):
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    dry = args.dry_run
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path); --dry-run exercises the launcher only")
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = "cpu" if dry else "cuda"
 
-    os.environ.setdefault("QATTN_STEP_EVENTS", "1")  # the library brackets attention launches with HIP events (bench only)
-    import quantumattention_amd as qa
-    from quantumattention_amd import _native
+    from quantumattention_amd.utils.shard import batch_shard, synthetic_qkv
 
     B, H, S, D = args.batch, args.heads, args.seq, args.dim
-    torch.manual_seed(rank)
-    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    shard = batch_shard(B * world, rank, world)   # this rank's slice of the global batch; no collective on the data path
+    if dry:
+        q, k, v = synthetic_qkv(shard, 2, 64, 64, device="cpu")
+    else:
+        q, k, v = synthetic_qkv(shard, H, S, D, device="cuda")
 
-    def step():
-        with qa.config.patch({"attention.fp8_format": args.fp8}):
+    if dry:
+        def step():
+            return torch.nn.functional.scaled_dot_product_attention(q, k, v)   # host stub: launcher / reduction test only
+
+        def sync():
+            pass
+    else:
+        import quantumattention_amd as qa
+        from quantumattention_amd import _native
+
+        cfg = {"attention.fp8_format": args.fp8, "attention.precision": args.precision}
+
+        def step():
             return qa.fp8_attn_func(q, k, v, is_causal=args.causal)
+
+        sync = torch.cuda.synchronize
 
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        return time.perf_counter() - t0
+
+    if dry:
+        elapsed = timed(step, args.warmup, args.steps)
+    else:
+        with qa.config.patch(cfg):
+            elapsed = timed(step, args.warmup, args.steps)
+    ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
-    # ---- dominant kernel alone (roofline): pre-quantised operands, HIP events on the launch stream
-    fp8_dtype = _native.FP8_DTYPE[args.fp8]
-    q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype)
+    line = {
+        "metric": "attention fwd TFLOP/s (fp8), quant pre-pass + fused attention",
+        "value": None, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": f"fp8_{args.fp8} (fp32 accumulate)", "data": "synthetic", "ranks_seen": ranks_seen,
+        "config": {"workload": f"B={B} H={H} S={S} D={D} {'causal' if args.causal else 'non-causal'} fp8({args.fp8}) "
+                               f"per GPU, bf16 in/out, head-wise scales, precision={args.precision} (BASELINE.json configs[1]"
+                               f"{'; batch-sharded B=%d total, configs[3] at 8 GPUs' % (B * world) if world > 1 else ''})",
+                   "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collectives"},
+    }
+    if dry:
+        line["value"] = flops(2, 2, 64, 64, 64, False) * world * args.steps / elapsed / 1e12
+        line["config"]["workload"] = "dry run (host stub)"
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
 
-    def attn_only():
-        return _native.fp8_attention_forward(q8, kf, vf, sq, sk, sv, Hkv=H, Skv=S, out_dtype=torch.bfloat16,
-                                             is_causal=args.causal)
+    f_gpu = flops(B, H, S, S, D, args.causal)
+    line["value"] = f_gpu * world * args.steps / elapsed / 1e12
+    line["frac_of_fp8_mfma_peak"] = line["value"] / (FP8_PEAK_TFLOPS * world)
 
-    def quant_only():
-        _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype)
-
-    def event_time(fn, n):
-        for _ in range(5):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n  # ms per launch
-
-    def attn_in_step(n):
-        """The attention launch's duration INSIDE the real step (the fused C entry: pre-pass -> attention), from the two HIP
-        events the library records on the launch stream around the attention launch (QATTN_STEP_EVENTS=1)."""
-        for _ in range(3):
-            step()
-        tot = 0.0
-        for _ in range(n):
-            step()
-            ms = _native.lib().qattn_debug_last_attention_ms()   # waits for this step's attention to finish
-            if ms < 0:
-                return None
-            tot += ms
-        return tot / n
-
-    attn_isolated_ms = event_time(attn_only, args.steps)   # the kernel launched back to back on pre-quantised operands
-    attn_ms = attn_in_step(args.steps)                     # what the roofline is computed from: the launch inside the step
-    if attn_ms is None:
-        attn_ms = attn_isolated_ms
-    quant_ms = event_time(quant_only, args.steps)
-    # informational: the same step replayed from a HIP graph (no launch gaps); `value` stays the eager API call
-    graph_ms = None
-    try:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step()
-        graph_ms = event_time(g.replay, args.steps)
-    except Exception as exc:  # capture is optional evidence, never fatal for the benchmark line
-        print(f"[bench] HIP graph capture skipped: {exc}", file=sys.stderr)
-
+    # ---- the dominant kernel (roofline), on rank 0
     if rank == 0:
-        f_gpu = flops(B, H, S, S, D, args.causal)
-        value = f_gpu * world * args.steps / elapsed / 1e12
+        L = _native.lib()
+        fp8_dtype = _native.FP8_DTYPE[args.fp8]
+
+        def event_time(fn, n):
+            for _ in range(5):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n  # ms per call
+
+        def attn_in_step(fn, n):
+            """Duration of the attention launches INSIDE the real step: the library brackets each of them with two HIP events
+            on its own launch stream (qattn_profile_attention) and returns their sum for the most recent step."""
+            L.qattn_profile_attention(1)
+            try:
+                for _ in range(3):
+                    fn()
+                tot = 0.0
+                for _ in range(n):
+                    fn()
+                    ms = L.qattn_last_attention_ms()   # waits for this step's attention launches
+                    if ms < 0:
+                        return None
+                    tot += ms
+                return tot / n
+            finally:
+                L.qattn_profile_attention(0)
+
+        with qa.config.patch(cfg):
+            q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype)
+
+            def attn_only():
+                return _native.fp8_attention_forward(q8, kf, vf, sq, sk, sv, Hkv=H, Skv=S, out_dtype=torch.bfloat16,
+                                                     is_causal=args.causal, precision=args.precision)
+
+            attn_isolated_ms = event_time(attn_only, args.steps)   # the kernel back to back on pre-quantised operands
+            attn_ms = attn_in_step(step, args.steps)               # the roofline figure: the launches inside the step
+            quant_ms = event_time(lambda: _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype), args.steps)
+            del q8, kf, vf
+            graph_ms = None
+            try:   # informational: the same step replayed from a HIP graph; `value` stays the eager API call
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    step()
+                graph_ms = event_time(g.replay, args.steps)
+            except Exception as exc:
+                print(f"[bench] HIP graph capture skipped: {exc}", file=sys.stderr)
+        if attn_ms is None:
+            attn_ms = attn_isolated_ms
         achieved = f_gpu / (attn_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and not args.causal and (B, H, S, D) == (4, 32, 4096, 128):
             traffic = json.load(open(tpath)).get("attn_fwd_hbm_bytes_per_launch")
-        line = {
-            "metric": "attention fwd TFLOP/s (fp8), quant pre-pass + fused attention",
-            "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": f"fp8_{args.fp8} (fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"B={B} H={H} S={S} D={D} {'causal' if args.causal else 'non-causal'} fp8({args.fp8}) "
-                                   f"per GPU, bf16 in/out, head-wise scales (BASELINE.json configs[1]"
-                                   f"{'; batch-sharded B=%d total' % (B * world) if world > 1 else ''})",
-                       "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collectives"},
-            "frac_of_fp8_mfma_peak": value / (FP8_PEAK_TFLOPS * world),
-            "attn_kernel_ms": attn_ms, "attn_kernel_isolated_ms": attn_isolated_ms, "quant_prepass_ms": quant_ms, "graph_replay_ms_per_step": graph_ms,
-            "roofline": {"kernel": "qattn::attn_fwd_kernel_v2<128,8,e4m3,e4m3,...,Q16> (fused QK^T/softmax/PV; timed inside the step)", "bound": "mfma", "achieved": achieved,
-                         "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP8_PEAK_TFLOPS,
-                         "traffic": traffic},
-        }
+            traffic_source = "profiles/traffic.json (rocprofv3 PMC passes of an earlier run of this command; not measured in this run)"
+        quant_alg_bytes = 3 * (2 + 1) * B * H * S * D   # read 2 B + write 1 B per element of q, k, v
+        line.update({
+            "attn_kernel_ms": attn_ms, "attn_kernel_isolated_ms": attn_isolated_ms, "quant_prepass_ms": quant_ms,
+            "quant_prepass_algorithmic_TBps": quant_alg_bytes / (quant_ms * 1e-3) / 1e12, "graph_replay_ms_per_step": graph_ms,
+            "roofline": {"kernel": kernel_label(D, args.fp8, args.causal, D == 128),
+                         "bound": "mfma", "achieved": achieved, "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP8_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source},
+        })
+        if world == 1 and not args.no_extras:
+            with qa.config.patch(cfg):
+                # sustained rate: >= 2 s of back-to-back steps, median of 20-step windows (power-limited kernels settle)
+                windows, t_end = [], time.perf_counter() + 2.0
+                while time.perf_counter() < t_end or len(windows) < 5:
+                    windows.append(timed(step, 0, 20) / 20 * 1e3)
+                windows.sort()
+                line["sustained_ms_per_step"] = windows[len(windows) // 2]
+                line["sustained_windows"] = len(windows)
+            # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
+            def extra(Bx, Hx, Sx, causal, fp8, n):
+                qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+                fn = lambda: qa.fp8_attn_func(qx, kx, vx, is_causal=causal)
+                with qa.config.patch({"attention.fp8_format": fp8, "attention.precision": args.precision}):
+                    ms = event_time(fn, n)
+                    ams = attn_in_step(fn, n)
+                fl = flops(Bx, Hx, Sx, Sx, D, causal)
+                return {"ms_per_step": ms, "attn_kernel_ms": ams, "step_TFLOPs": fl / (ms * 1e-3) / 1e12,
+                        "attn_frac_of_peak": None if not ams else fl / (ams * 1e-3) / 1e12 / FP8_PEAK_TFLOPS}
+            if (B, H, S, D) == (4, 32, 4096, 128) and not args.causal:
+                line["c3_causal_B4_H32_S4096"] = extra(4, 32, 4096, True, "e4m3", 20)
+                line["c5_causal_e5m2_B4_H40_S16384"] = extra(4, 40, 16384, True, "e5m2", 5)
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, q, k, v)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define QATTN_ABI_VERSION 3
+#define QATTN_ABI_VERSION 4
 
 /* element formats */
 #define QATTN_FMT_E4M3 0 /* OCP float8_e4m3fn  (torch.float8_e4m3fn) */
@@ -66,6 +66,27 @@ extern "C" {
  * quotient rounded to the input dtype), 1 = the reference's eager arithmetic (everything in the input dtype). */
 #define QATTN_NUMERICS_COMPILED 0
 #define QATTN_NUMERICS_EAGER 1
+
+/* how the softmax probabilities P enter the second fp8 GEMM.  The reference keeps P (and V) in 16 bit
+ * (src/quantum_attn/tk/attention.py:72,286,318); here P is e4m3, and ONE e4m3 term (3 mantissa bits) is accurate enough
+ * only for rows whose weight is spread over many keys:
+ *   AUTO     (default) one-term P, checked per row: a 256-row query block in which some row's largest softmax weight
+ *            exceeds 1/24 (R = l / p_max < 24) is recomputed with two-term (hi + lo) P before/over its one-term result.
+ *   FAST     one-term P wherever a row sees >= 1024 keys (what other fp8 attention kernels do); no check.
+ *   ACCURATE two-term P everywhere (~bf16-P accuracy, 1.5x the matrix work).
+ * In every mode query blocks that see fewer than 1024 keys (short sequences, early causal rows) use two-term P. */
+#define QATTN_PRECISION_AUTO 0
+#define QATTN_PRECISION_FAST 1
+#define QATTN_PRECISION_ACCURATE 2
+
+/* layout / convention of the optional log-sum-exp output:
+ *   NATURAL   dense fp32 [B,Hq,Sq], ln sum_j exp(score_j) of the scaled scores
+ *   REFERENCE the vector the reference defines in its (disabled) epilogue, tk/attention.py:333-346,439-446:
+ *             L = -(ln l + m ln2) * sqrt(D) = -sqrt(D) * NATURAL, rows of consecutive (b,h) spaced
+ *             qattn_lse_row_stride(Sq, REFERENCE) = ceil(Sq*4/16)*16/4 floats apart (row padded to 16 bytes).
+ *             (The reference's constants are -8 for D = 64 and -11.3137 = -sqrt(128) for every other D; here -sqrt(D).) */
+#define QATTN_LSE_NATURAL 0
+#define QATTN_LSE_REFERENCE 1
 
 /* error codes */
 #define QATTN_OK 0
@@ -121,32 +142,38 @@ int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S
  *   k8        [B,Hkv,Skv,D] fp8 (qk_fmt), QATTN_LAYOUT_KFRAG
  *   v8        [B,Hkv,Skv,D] fp8 (v_fmt),  QATTN_LAYOUT_VFRAG
  *   out       [B,Hq,Sq,D]   bf16 or fp16 (out_fmt), row-major, written in full
- *   lse       NULL, or fp32 [B,Hq,Sq]: natural-log-sum-exp of the scaled scores (the per-row vector the reference
- *             defines but disables, tk/attention.py:333-346)
+ *   lse       NULL, or fp32 log-sum-exp of the scaled scores per query row in `lse_layout` (B*Hq rows of
+ *             qattn_lse_row_stride(Sq, lse_layout) floats) -- the per-row vector the reference defines but disables
  *   scale_q   fp32 [B,Hq] (head-wise) or [B,Hq,Sq] (token-wise);  scale_k likewise with Hkv,Skv
  *   scale_v   fp32 [B,Hkv] or NULL (= 1.0)
  *   sm_scale  softmax scale; <= 0 selects 1/sqrt(D) (the reference hard-wires it, tk/attention.py:208-210)
  *   is_causal keep key j <= query i (aten top-left alignment; the reference requires Sq == Skv, tests/test_interface.py:32)
- * Both GEMMs run on v_mfma_f32_32x32x64_f8f6f4; P is quantised to e4m3 (two-term hi+lo where few keys are visible).
- * Accumulation, running max/sum and the softmax are fp32.
+ *   precision QATTN_PRECISION_*
+ *   workspace device scratch of qattn_attention_workspace_bytes(B, Hq, Sq) bytes (one word per 256-row query block;
+ *             needed for QATTN_PRECISION_AUTO, may be NULL otherwise)
+ * Both GEMMs run on v_mfma_f32_32x32x64_f8f6f4; accumulation, running max/sum and the softmax are fp32.
  */
+size_t qattn_attention_workspace_bytes(int B, int Hq, int Sq);
+size_t qattn_lse_row_stride(int Sq, int lse_layout);
 int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, void* out, float* lse,
                                 const float* scale_q, const float* scale_k, const float* scale_v, int B, int Hq,
                                 int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt, int scale_mode,
-                                int is_causal, float sm_scale, void* stream);
+                                int is_causal, float sm_scale, int precision, int lse_layout, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /*
  * The whole step of `_fp8_attention_wrapper` for 16-bit inputs (nn.py:394-430: quantise q and k, then the fp8 op) in one
  * call: pre-pass (qattn_quant_qkv_fp8 semantics) + attention (qattn_fp8_attention_forward semantics, no LSE) on `stream`.
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
- * qattn_quant_qkv_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16, head-wise) the
- * pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read and one write
- * of Q; results are bit-identical to the two separate calls.
+ * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
+ * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
+ * and one write of Q.  Results are bit-identical to the separate calls.
  */
+size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int Hkv, int Sq);
 int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8, void* k8,
                                       void* v8, float* scale_q, float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq,
                                       int Skv, int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
-                                      void* workspace, size_t workspace_bytes, void* stream);
+                                      int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * 16-bit sibling path: the non-fp8 build of the same kernel (TK_ATTN_IS_FP8 undefined, tk/attention.py:212,238-240,
@@ -154,16 +181,21 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
  * (src/quantum_attn/ops.py:17-45).  q/out row-major [B,Hq,Sq,D] bf16 or fp16 (`fmt`); k16/v16 are the key/value
  * tensors re-laid by qattn_pack16 into QATTN_LAYOUT_K16FRAG / QATTN_LAYOUT_V16FRAG (qattn_16bit_tensor_bytes bytes).
  * D in {64,128,256}.  Both GEMMs run on v_mfma_f32_32x32x16_{bf16,f16}; softmax, running max/sum and accumulation fp32.
+ * fast_exp = 0 (default): exact exp2 as the reference; 1: linear-mantissa 2^x (1.8 % rms error per weight) for rows that
+ * see >= 1024 keys -- only for rows known to be flat.  lse: NULL or dense fp32 [B,Hq,Sq] (QATTN_LSE_NATURAL).
  */
 size_t qattn_16bit_tensor_bytes(int layout, int B, int H, int S, int D);
 int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H, int S, int D, int out_layout, void* stream);
 int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, void* out, float* lse, int B, int Hq,
-                               int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, void* stream);
+                               int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, int fast_exp,
+                               void* stream);
 
-/* Development aid (not part of the drop-in surface): with QATTN_STEP_EVENTS=1 in the environment every attention launch is
- * bracketed by two HIP events on its stream; this returns the milliseconds between them for the most recent launch
- * (synchronises on the second event), or a negative value when disabled. */
-float qattn_debug_last_attention_ms(void);
+/* Measurement aid for bench.py (not part of the drop-in surface).  qattn_profile_attention(1) makes every following
+ * attention launch on the calling thread's current device be bracketed by two HIP events on its own stream;
+ * qattn_last_attention_ms() returns the milliseconds between them for the most recent launch (it synchronises on the
+ * second event), or a negative value when profiling is off.  Off by default; no environment variable changes results. */
+void qattn_profile_attention(int enable);
+float qattn_last_attention_ms(void);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,9 @@ FMT_E4M3, FMT_E5M2, FMT_BF16, FMT_FP16 = 0, 1, 2, 3
 SCALE_HEAD, SCALE_TOKEN = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_KFRAG, LAYOUT_VFRAG, LAYOUT_K16FRAG, LAYOUT_V16FRAG = 0, 1, 2, 3, 4
 NUMERICS = {"compiled": 0, "eager": 1}
-ABI_VERSION = 3
+ABI_VERSION = 4
+PRECISION = {"auto": 0, "fast": 1, "accurate": 2}
+LSE_NATURAL, LSE_REFERENCE = 0, 1
 
 _FMT_OF_DTYPE = {
     torch.float8_e4m3fn: FMT_E4M3,
@@ -27,7 +29,8 @@ EXPORTS = (
     "qattn_quant_workspace_bytes", "qattn_quant_fp8", "qattn_quant_qkv_workspace_bytes", "qattn_quant_qkv_fp8",
     "qattn_pack_fp8", "qattn_fp8_attention_forward",
     "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16", "qattn_fp8_quant_attention_forward",
-    "qattn_debug_last_attention_ms",
+    "qattn_attention_workspace_bytes", "qattn_lse_row_stride", "qattn_fp8_quant_attention_workspace_bytes",
+    "qattn_profile_attention", "qattn_last_attention_ms",
 )
 
 _lib = None
@@ -61,21 +64,64 @@ def lib() -> ctypes.CDLL:
     L.qattn_quant_qkv_fp8.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, sz, vp]
     L.qattn_pack_fp8.restype = i
     L.qattn_pack_fp8.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.qattn_attention_workspace_bytes.restype = sz
+    L.qattn_attention_workspace_bytes.argtypes = [i, i, i]
+    L.qattn_lse_row_stride.restype = sz
+    L.qattn_lse_row_stride.argtypes = [i, i]
     L.qattn_fp8_attention_forward.restype = i
-    L.qattn_fp8_attention_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp]
+    L.qattn_fp8_attention_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, i, i, vp, sz, vp]
     L.qattn_16bit_tensor_bytes.restype = sz
     L.qattn_16bit_tensor_bytes.argtypes = [i, i, i, i, i]
     L.qattn_pack16.restype = i
     L.qattn_pack16.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.qattn_attention_forward_16.restype = i
-    L.qattn_attention_forward_16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp]
-    L.qattn_debug_last_attention_ms.restype = ctypes.c_float
+    L.qattn_attention_forward_16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, vp]
+    L.qattn_profile_attention.restype = None
+    L.qattn_profile_attention.argtypes = [i]
+    L.qattn_last_attention_ms.restype = ctypes.c_float
+    L.qattn_fp8_quant_attention_workspace_bytes.restype = sz
+    L.qattn_fp8_quant_attention_workspace_bytes.argtypes = [i, i, i, i]
     L.qattn_fp8_quant_attention_forward.restype = i
-    L.qattn_fp8_quant_attention_forward.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, vp, sz, vp]
+    L.qattn_fp8_quant_attention_forward.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp]
     if L.qattn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libqattn_hip.so ABI {L.qattn_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = L
     return L
+
+
+def _require(cond: bool, what: str) -> None:
+    """Argument checks of the binding raise (they must survive `python -O`, unlike assert)."""
+    if not cond:
+        raise ValueError(what)
+
+
+def _scale_mode(scaling: str) -> int:
+    _require(scaling in ("head-wise", "token-wise"), f"Unsupported scaling_method: {scaling}")
+    return SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
+
+
+def _check_qkv(q, k, v):
+    """q [B,Hq,Sq,D], k / v [B,Hkv,Skv,D] on one device with one 16-bit dtype (tk/attention.py:362-400)."""
+    _require(q.is_cuda and q.dim() == 4 and k.dim() == 4 and v.dim() == 4, "query, key and value must be 4-D device tensors")
+    _require(q.device == k.device == v.device, "query, key and value must be on the same device")
+    _require(q.dtype == k.dtype == v.dtype, f"query, key and value must share a dtype, got {q.dtype}, {k.dtype}, {v.dtype}")
+    B, Hq, Sq, D = q.shape
+    _require(k.shape == v.shape, f"key and value shapes differ: {tuple(k.shape)} vs {tuple(v.shape)}")
+    _require(k.shape[0] == B and k.shape[3] == D, f"key/value batch or head_dim {tuple(k.shape)} do not match the query {tuple(q.shape)}")
+    Hkv, Skv = k.shape[1], k.shape[2]
+    _require(Hkv > 0 and Hq % Hkv == 0, f"Hq={Hq} is not a multiple of Hkv={Hkv}")
+    return B, Hq, Hkv, Sq, Skv, D
+
+
+def _check_scales(scale_q, scale_k, scale_v, mode, B, Hq, Hkv, Sq, Skv, device) -> None:
+    """fp32, on `device`, exactly [B,H] (head-wise) or [B,H,S] (token-wise): tk/attention.py:402-414."""
+    want_q = (B, Hq) if mode == SCALE_HEAD else (B, Hq, Sq)
+    want_k = (B, Hkv) if mode == SCALE_HEAD else (B, Hkv, Skv)
+    for name, s, want in (("scale_q", scale_q, want_q), ("scale_k", scale_k, want_k), ("scale_v", scale_v, (B, Hkv))):
+        if s is None and name == "scale_v":
+            continue
+        _require(s is not None and s.dtype == torch.float32 and s.device == device and tuple(s.shape) == want,
+                 f"{name} must be float32 {want} on {device}")
 
 
 def _check(rc: int, what: str) -> None:
@@ -102,11 +148,11 @@ def quant_fp8(x: torch.Tensor, *, scaling: str = "head-wise", fp8_dtype=torch.fl
               layout: int = LAYOUT_ROWMAJOR, numerics: str = "compiled") -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16/fp16 [B,H,S,D] -> (fp8 payload, fp32 scale).  Row-major payloads come back as an fp8 tensor of
     x's shape; fragment layouts as a flat uint8 buffer (their layout is private to the library)."""
-    assert x.is_cuda and x.dim() == 4
+    _require(x.is_cuda and x.dim() == 4, "quant_fp8 needs a 4-D device tensor")
     x = x.contiguous()
     B, H, S, D = x.shape
     L = lib()
-    mode = SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
+    mode = _scale_mode(scaling)
     nbytes = L.qattn_fp8_tensor_bytes(layout, B, H, S, D)
     with torch.cuda.device(x.device):
         if layout == LAYOUT_ROWMAJOR:
@@ -126,12 +172,10 @@ def quant_fp8(x: torch.Tensor, *, scaling: str = "head-wise", fp8_dtype=torch.fl
 def quant_qkv_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scaling: str = "head-wise",
                   fp8_dtype=torch.float8_e4m3fn, numerics: str = "compiled"):
     """Fused pre-pass: (q8 row-major fp8, k_frag, v_frag, scale_q, scale_k, scale_v) in two launches."""
-    assert q.is_cuda and q.dim() == 4 and k.shape == v.shape and q.dtype == k.dtype == v.dtype
+    B, Hq, Hkv, Sq, Skv, D = _check_qkv(q, k, v)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    B, Hq, Sq, D = q.shape
-    _, Hkv, Skv, _ = k.shape
     L = lib()
-    mode = SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
+    mode = _scale_mode(scaling)
     dev = q.device
     with torch.cuda.device(dev):
         q8 = torch.empty((B, Hq, Sq, D), dtype=fp8_dtype, device=dev)
@@ -152,7 +196,7 @@ def quant_qkv_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scaling:
 
 def pack_fp8(x8: torch.Tensor, layout: int) -> torch.Tensor:
     """row-major fp8 [B,H,S,D] -> flat uint8 buffer in KFRAG / VFRAG layout."""
-    assert x8.is_cuda and x8.dim() == 4 and x8.dtype.itemsize == 1
+    _require(x8.is_cuda and x8.dim() == 4 and x8.dtype.itemsize == 1, "pack_fp8 needs a 4-D fp8 device tensor")
     x8 = x8.contiguous()
     B, H, S, D = x8.shape
     L = lib()
@@ -166,29 +210,42 @@ def pack_fp8(x8: torch.Tensor, layout: int) -> torch.Tensor:
 def fp8_attention_forward(q8: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Tensor, scale_q: torch.Tensor,
                           scale_k: torch.Tensor, scale_v: Optional[torch.Tensor], *, Hkv: int, Skv: int,
                           out_dtype: torch.dtype, is_causal: bool, scaling: str = "head-wise",
-                          sm_scale: float = 0.0, return_lse: bool = False):
-    """q8: row-major fp8 [B,Hq,Sq,D]; k_frag / v_frag: fragment-layout buffers for [B,Hkv,Skv,D]."""
-    assert q8.is_cuda and q8.dim() == 4
+                          sm_scale: float = 0.0, return_lse: bool = False, precision: str = "auto",
+                          lse_layout: int = LSE_NATURAL):
+    """q8: row-major fp8 [B,Hq,Sq,D]; k_frag / v_frag: fragment-layout buffers for [B,Hkv,Skv,D].
+    return_lse: also the log-sum-exp rows; LSE_REFERENCE gives the reference-defined strided view (include/qattn.h)."""
+    _require(q8.is_cuda and q8.dim() == 4, "fp8_attention_forward needs a 4-D device query")
     q8 = q8.contiguous()
     B, Hq, Sq, D = q8.shape
     L = lib()
-    mode = SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
+    mode = _scale_mode(scaling)
+    _check_scales(scale_q, scale_k, scale_v, mode, B, Hq, Hkv, Sq, Skv, q8.device)
+    _require(k_frag.numel() * k_frag.element_size() >= L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, Hkv, Skv, D)
+             and v_frag.numel() * v_frag.element_size() >= L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D),
+             "k_frag / v_frag are smaller than the fragment layouts of [B,Hkv,Skv,D]")
     with torch.cuda.device(q8.device):
         out = torch.empty((B, Hq, Sq, D), dtype=out_dtype, device=q8.device)
-        lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q8.device) if return_lse else None
+        lse = None
+        if return_lse:
+            stride = L.qattn_lse_row_stride(Sq, lse_layout)
+            lse = torch.empty((B, Hq, stride), dtype=torch.float32, device=q8.device)
+        ws_bytes = L.qattn_attention_workspace_bytes(B, Hq, Sq)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q8.device)
         rc = L.qattn_fp8_attention_forward(
             q8.data_ptr(), k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
             scale_q.contiguous().data_ptr(), scale_k.contiguous().data_ptr(),
             _ptr(scale_v.contiguous() if scale_v is not None else None),
             B, Hq, Hkv, Sq, Skv, D, fmt_of(q8.dtype), fmt_of(q8.dtype), fmt_of(out_dtype), mode, int(is_causal),
-            float(sm_scale), _stream(q8))
+            float(sm_scale), PRECISION[precision], lse_layout, ws.data_ptr(), ws_bytes, _stream(q8))
     _check(rc, "qattn_fp8_attention_forward")
-    return (out, lse) if return_lse else out
+    if return_lse:
+        return out, lse[..., :Sq]  # [B,Hq,Sq] view; strides (Hq*ld, ld, 1) with ld = the padded row for LSE_REFERENCE
+    return out
 
 
 def pack16(x: torch.Tensor, layout: int) -> torch.Tensor:
     """row-major bf16/fp16 [B,H,S,D] -> flat uint8 buffer in K16FRAG / V16FRAG layout."""
-    assert x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
+    _require(x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16), "pack16 needs a 4-D bf16/fp16 device tensor")
     x = x.contiguous()
     B, H, S, D = x.shape
     L = lib()
@@ -200,32 +257,34 @@ def pack16(x: torch.Tensor, layout: int) -> torch.Tensor:
 
 
 def attention_forward_16(q: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Tensor, *, Hkv: int, Skv: int,
-                         is_causal: bool, sm_scale: float = 0.0, return_lse: bool = False):
+                         is_causal: bool, sm_scale: float = 0.0, return_lse: bool = False, fast_exp: bool = False):
     """q: row-major bf16/fp16 [B,Hq,Sq,D]; k_frag / v_frag: K16FRAG / V16FRAG buffers for [B,Hkv,Skv,D]."""
-    assert q.is_cuda and q.dim() == 4
+    _require(q.is_cuda and q.dim() == 4, "attention_forward_16 needs a 4-D device query")
     q = q.contiguous()
     B, Hq, Sq, D = q.shape
     L = lib()
+    _require(k_frag.numel() * k_frag.element_size() >= L.qattn_16bit_tensor_bytes(LAYOUT_K16FRAG, B, Hkv, Skv, D)
+             and v_frag.numel() * v_frag.element_size() >= L.qattn_16bit_tensor_bytes(LAYOUT_V16FRAG, B, Hkv, Skv, D),
+             "k_frag / v_frag are smaller than the fragment layouts of [B,Hkv,Skv,D]")
     with torch.cuda.device(q.device):
         out = torch.empty_like(q)
         lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if return_lse else None
         rc = L.qattn_attention_forward_16(q.data_ptr(), k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
                                           B, Hq, Hkv, Sq, Skv, D, fmt_of(q.dtype), int(is_causal), float(sm_scale),
-                                          _stream(q))
+                                          int(fast_exp), _stream(q))
     _check(rc, "qattn_attention_forward_16")
     return (out, lse) if return_lse else out
 
 
 def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, is_causal: bool, scaling: str = "head-wise",
-                                fp8_dtype=torch.float8_e4m3fn, numerics: str = "compiled", sm_scale: float = 0.0) -> torch.Tensor:
+                                fp8_dtype=torch.float8_e4m3fn, numerics: str = "compiled", sm_scale: float = 0.0,
+                                precision: str = "auto") -> torch.Tensor:
     """16-bit q, k, v -> attention output: the quant pre-pass and the attention launch(es) in ONE C call
     (qattn_fp8_quant_attention_forward); the pre-pass skips Q where the attention kernel quantises it itself."""
-    assert q.is_cuda and q.dim() == 4 and k.shape == v.shape and q.dtype == k.dtype == v.dtype
+    B, Hq, Hkv, Sq, Skv, D = _check_qkv(q, k, v)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    B, Hq, Sq, D = q.shape
-    _, Hkv, Skv, _ = k.shape
     L = lib()
-    mode = SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
+    mode = _scale_mode(scaling)
     dev = q.device
     with torch.cuda.device(dev):
         out = torch.empty_like(q)
@@ -235,11 +294,11 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         sq = torch.empty((B, Hq) if mode == SCALE_HEAD else (B, Hq, Sq), dtype=torch.float32, device=dev)
         sk = torch.empty((B, Hkv) if mode == SCALE_HEAD else (B, Hkv, Skv), dtype=torch.float32, device=dev)
         sv = torch.empty((B, Hkv), dtype=torch.float32, device=dev)
-        ws_bytes = L.qattn_quant_qkv_workspace_bytes(B, Hq, Hkv)
+        ws_bytes = L.qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         rc = L.qattn_fp8_quant_attention_forward(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
             vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
-            NUMERICS[numerics], int(is_causal), float(sm_scale), ws.data_ptr(), ws_bytes, _stream(q))
+            NUMERICS[numerics], int(is_causal), float(sm_scale), PRECISION[precision], ws.data_ptr(), ws_bytes, _stream(q))
     _check(rc, "qattn_fp8_quant_attention_forward")
     return out

@@ -14,11 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libqattn_hip.so")
-SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v3.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip"]
+SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip"]
+# `--dev` builds libqattn_hip_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
+# QATTN_* environment switches.  The product library contains none of them.
+DEV_SOURCES = []
 ARCH = "gfx950"
-# one-wave-per-SIMD kernels (up to 512 registers): keep MFMA results that the VALU reads in architectural VGPRs instead
-# of the default AGPR-form MFMAs, which cost ~146 v_accvgpr copies per iteration
-EXTRA_FLAGS = {"qattn_attn_v3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-ffp-contract=off", "-Wall", "-Wno-unused-command-line-argument", "-Wno-unused-value", "-Wno-pass-failed"]
 
@@ -37,31 +38,33 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = False) -> str:
-    os.makedirs(BUILD, exist_ok=True)
+def build(force: bool = False, save_temps: bool = False, verbose: bool = False, dev: bool = False) -> str:
+    build_dir = BUILD + ("_dev" if dev else "")
+    lib = LIB.replace(".so", "_dev.so") if dev else LIB
+    os.makedirs(build_dir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "qattn.h"))
     objs, jobs = [], []
-    for src in SOURCES:
+    for src in SOURCES + (DEV_SOURCES if dev else []):
         s = os.path.join(CSRC, src)
-        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        o = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + (["-DQATTN_DEV"] if dev else []) + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=BUILD)
-    with ThreadPoolExecutor(max_workers=4) as ex:
+        subprocess.check_call(cmd, cwd=build_dir)
+    with ThreadPoolExecutor(max_workers=5) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True, dev="--dev" in sys.argv))

@@ -23,6 +23,17 @@ class attention:
     fp8_format = os.getenv("QUANTUM_ATTN_FP8_FORMAT", "e4m3")
     quant_numerics = os.getenv("QUANTUM_ATTN_QUANT_NUMERICS", "compiled")
 
+    # how the probabilities P enter the second fp8 GEMM:
+    #   "auto"     one-term e4m3 P where the softmax row is spread over enough keys; every 256-row query block in which a
+    #              row turns out to be peaked (few keys carry the weight) is recomputed with two-term (hi + lo) P
+    #   "fast"     one-term P everywhere (what other fp8 attention kernels do); error grows with the sharpness of the rows
+    #   "accurate" two-term P everywhere (about bf16-P accuracy, ~1.5x the matrix work)
+    precision = os.getenv("QUANTUM_ATTN_PRECISION", "auto")
+
+    # 16-bit sibling path (attn_func): False = exact v_exp_f32 softmax (default); True = the linear-mantissa 2^x
+    # approximation for rows that see >= 1024 keys (+9 % speed, 1.8 % rms error in P: fine for flat rows only)
+    fast_exp16 = os.getenv("QUANTUM_ATTN_FAST_EXP16") == "1"
+
 
 from torch.utils._config_module import install_config_module  # noqa: E402
 

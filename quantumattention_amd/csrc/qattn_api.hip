@@ -1,107 +1,153 @@
 // qattn_api.hip -- C-ABI entry points of libqattn_hip.so that are not in qattn_quant.hip (include/qattn.h).
-#include <cstdlib>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#ifdef QATTN_DEV
 #include <algorithm>
 #include <vector>
+#endif
 
 #include "qattn_attn.h"
 
 using namespace qattn;
 
-// Development switch for A/B runs: QATTN_KERNEL_VARIANT = 1 (first, non-pipelined structure), 2 (default for D = 128:
-// 8 waves x 32 rows, pipelined), 3 (experimental: 4 waves x 64 rows; correct but register-allocation bound).
-// QATTN_EXACT_EXP=1 disables the byte-exponential fast path (see qattn_attn_v2.hip).
-static int exact_exp() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("QATTN_EXACT_EXP");
-        v = e ? atoi(e) : 0;
+namespace {
+
+#ifdef QATTN_DEV
+// Development switches (only in `build.py --dev` libraries; the product library reads no environment variable):
+//   QATTN_KERNEL_VARIANT=4  the templated kernel (qattn_attn_v4.hip) for D = 128 too
+//   QATTN_EXACT_EXP=1       exact v_exp_f32 + RNE conversion instead of the byte exponential
+//   QATTN_V2_WAVES / QATTN_V2_LDS / QATTN_V2_DBG / QATTN_TWO_TERM_KEYS / QATTN_PEAK_R0 / QATTN_NO_Q_FUSION
+struct DevEnv {
+    int variant, exact_exp, waves, lds, dbg, two_term_keys, no_q_fusion;
+    float peak_r0;
+    DevEnv() {
+        auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+        variant = geti("QATTN_KERNEL_VARIANT", 2); exact_exp = geti("QATTN_EXACT_EXP", 0); waves = geti("QATTN_V2_WAVES", 8);
+        lds = geti("QATTN_V2_LDS", 0); dbg = geti("QATTN_V2_DBG", 0); two_term_keys = geti("QATTN_TWO_TERM_KEYS", kTwoTermKeys);
+        no_q_fusion = geti("QATTN_NO_Q_FUSION", 0);
+        const char* e = getenv("QATTN_PEAK_R0");
+        peak_r0 = e ? (float)atof(e) : kPeakR0;
     }
-    return v;
+};
+const DevEnv& dev_env() { static const DevEnv e; return e; }   // read once, at the first call
+#endif
+
+// Per-device events of the bench.py measurement aid (qattn_profile_attention), created on first use.
+constexpr int kMaxDevices = 64;
+struct DeviceState {
+    bool ready = false;
+    hipEvent_t prof[2] = {};   // recorded around the attention launches of a call, on their stream
+    bool recorded = false;
+};
+DeviceState g_dev[kMaxDevices];
+std::mutex g_mutex;
+thread_local int t_profile = 0;
+
+DeviceState* device_state(bool may_create) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    DeviceState& s = g_dev[dev];
+    if (s.ready) return &s;
+    if (!may_create) return nullptr;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (s.ready) return &s;
+    if (hipEventCreate(&s.prof[0]) != hipSuccess || hipEventCreate(&s.prof[1]) != hipSuccess) return nullptr;
+    s.ready = true;
+    return &s;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
+bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &status) == hipSuccess && status != hipStreamCaptureStatusNone;
 }
 
-static int kernel_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("QATTN_KERNEL_VARIANT");
-        v = e ? atoi(e) : 2;
-    }
-    return v;
-}
+struct AttnCall {
+    const void *q8, *k8, *v8;
+    void* out;
+    float* lse;
+    const float *scale_q, *scale_k, *scale_v;
+    int B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode, is_causal;
+    float sm_scale;
+    int precision, lse_layout;
+    unsigned* flags;   // nullptr or one word per (b, h, 256-row block) of THIS call
+    const void* q16;   // fused step (else nullptr): bf16 Q, quantised in the kernel from q_amax_bits; sq_out is written
+    const unsigned* q_amax_bits;
+    float* sq_out;
+    int q_numerics;
+};
 
-static hipEvent_t g_ev[2] = {nullptr, nullptr};
-
-// development (QATTN_STEP_EVENTS=1): milliseconds between the HIP events recorded right before and right after the most
-// recent attention launch(es) on their stream; synchronises on the second event.  Used by bench.py to time the attention
-// kernel inside the fused step without a profiler.
-extern "C" float qattn_debug_last_attention_ms(void) {
-    if (!g_ev[0]) return -1.0f;
-    float ms = -1.0f;
-    if (hipEventSynchronize(g_ev[1]) != hipSuccess || hipEventElapsedTime(&ms, g_ev[0], g_ev[1]) != hipSuccess) return -1.0f;
-    return ms;
-}
-
-// q16 != nullptr: the fused step -- Q is the bf16 tensor, quantised inside the kernel from q_amax_bits; scale_q is an OUTPUT.
-static int attention_impl(const void* q8, const void* k8, const void* v8, void* out, float* lse, const float* scale_q,
-                          const float* scale_k, const float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt,
-                          int v_fmt, int out_fmt, int scale_mode, int is_causal, float sm_scale, const void* q16,
-                          const unsigned* q_amax_bits, float* sq_out, int q_numerics, void* stream) {
+// launches the attention kernel(s) of one call on `st`; ds != nullptr: bracket them with the profile events
+int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     // argument checks mirror the reference launcher's TORCH_CHECKs (tk/attention.py:362-415)
-    if ((!q8 && !q16) || !k8 || !v8 || !out || (!scale_q && !q16) || !scale_k) return QATTN_ERR_INVALID_ARG;
-    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
-    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;  // nn.py:45-49
-    if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;                    // tk/attention.py:398-399
-    if (qk_fmt != QATTN_FMT_E4M3 && qk_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (v_fmt != qk_fmt) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (out_fmt != QATTN_FMT_BF16 && out_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    if ((!a.q8 && !a.q16) || !a.k8 || !a.v8 || !a.out || (!a.scale_q && !a.q16) || !a.scale_k) return QATTN_ERR_INVALID_ARG;
+    if (a.B <= 0 || a.Hq <= 0 || a.Hkv <= 0 || a.Sq <= 0 || a.Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    if (a.D != 64 && a.D != 128 && a.D != 256) return QATTN_ERR_UNSUPPORTED_DIM;  // nn.py:45-49
+    if (a.Hq % a.Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;                      // tk/attention.py:398-399
+    if (a.qk_fmt != QATTN_FMT_E4M3 && a.qk_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (a.v_fmt != a.qk_fmt) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (a.out_fmt != QATTN_FMT_BF16 && a.out_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (a.scale_mode != QATTN_SCALE_HEAD && a.scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    if (a.precision != QATTN_PRECISION_AUTO && a.precision != QATTN_PRECISION_FAST && a.precision != QATTN_PRECISION_ACCURATE) return QATTN_ERR_INVALID_ARG;
+    if (a.lse_layout != QATTN_LSE_NATURAL && a.lse_layout != QATTN_LSE_REFERENCE) return QATTN_ERR_INVALID_ARG;
     AttnParams p;
-    p.q = (const unsigned char*)q8; p.k = (const unsigned char*)k8; p.v = (const unsigned char*)v8;
-    p.out = out; p.lse = lse; p.sq = scale_q; p.sk = scale_k; p.sv = scale_v;
-    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
-    const bool use_v4_full = D != 128;  // D = 64 / 256: the templated three-waves kernel covers every case
-    const bool use_v3 = !use_v4_full && kernel_variant() == 3;
-    p.waves = (use_v3 || use_v4_full) ? kWaves : env_int("QATTN_V2_WAVES", 8);  // v3 workgroups also cover 256 rows
-    p.lds_pad = env_int("QATTN_V2_LDS", 0);
-    p.dbg = env_int("QATTN_V2_DBG", 0);
-    p.dbg_buf = nullptr;
+    memset(&p, 0, sizeof(p));
+    p.q = (const unsigned char*)a.q8; p.k = (const unsigned char*)a.k8; p.v = (const unsigned char*)a.v8;
+    p.out = a.out; p.lse = a.lse; p.sq = a.scale_q; p.sk = a.scale_k; p.sv = a.scale_v;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Skv = a.Skv;
+    p.nqb = ceil_div(a.Sq, kQPerWG);
+    p.nchunks = ceil_div(a.Skv, 64);
+    p.out_fmt = a.out_fmt;
+    p.xcd_remap = ((a.B * a.Hq) % 8 == 0) ? 1 : 0;
+    const float sm = a.sm_scale > 0.0f ? a.sm_scale : 1.0f / sqrtf((float)a.D);
+    p.sm_log2e = sm * 1.4426950408889634f;
+    p.precision = a.precision;
+    p.two_term_keys = kTwoTermKeys;
+    p.peak_r0 = a.precision == QATTN_PRECISION_AUTO ? kPeakR0 : 0.0f;
+    p.flags = a.flags;
+    p.lse_stride = (long)qattn_lse_row_stride(a.Sq, a.lse_layout);
+    p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
+    p.q16 = (const unsigned char*)a.q16; p.q_amax_bits = a.q_amax_bits; p.sq_out = a.sq_out; p.q_numerics = a.q_numerics;
+    bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
+#ifdef QATTN_DEV
+    const DevEnv& e = dev_env();
+    p.exact_exp = e.exact_exp;
+    p.two_term_keys = e.two_term_keys;
+    if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = e.peak_r0;
+    p.waves = !use_v2 ? kWaves : e.waves;
+    p.nqb = ceil_div(a.Sq, p.waves * kQPerWave);
+    p.lds_pad = e.lds; p.dbg = e.dbg; p.dbg_buf = nullptr;
     static unsigned long long* dbg_dev = nullptr;
-    const long n_dbg_waves = (long)B * Hq * ceil_div(Sq, p.waves * kQPerWave) * (use_v3 ? 4 : p.waves);
+    const long n_dbg_waves = (long)a.B * a.Hq * p.nqb * p.waves;
     if (p.dbg & 16) {
         if (!dbg_dev) (void)hipMalloc(&dbg_dev, sizeof(unsigned long long) * 2 * (1 << 20));
         p.dbg_buf = dbg_dev;
-        (void)hipMemsetAsync(dbg_dev, 0, sizeof(unsigned long long) * 2 * n_dbg_waves, (hipStream_t)stream);
+        (void)hipMemsetAsync(dbg_dev, 0, sizeof(unsigned long long) * 2 * n_dbg_waves, st);
     }
-    p.nqb = ceil_div(Sq, p.waves * kQPerWave);
-    p.nchunks = ceil_div(Skv, 64);
-    p.out_fmt = out_fmt;
-    p.xcd_remap = ((B * Hq) % 8 == 0) ? 1 : 0;
-    const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
-    p.sm_log2e = sm * 1.4426950408889634f;
-    p.exact_exp = exact_exp();
-    p.use_v4 = kernel_variant() == 4 ? 1 : 0;
-    p.q16 = (const unsigned char*)q16; p.q_amax_bits = q_amax_bits; p.sq_out = sq_out; p.q_numerics = q_numerics;
-    hipStream_t st = (hipStream_t)stream;
-    static const bool step_events = env_int("QATTN_STEP_EVENTS", 0) != 0;  // development: time this launch inside a longer sequence
-    if (step_events) {
-        if (!g_ev[0]) { (void)hipEventCreate(&g_ev[0]); (void)hipEventCreate(&g_ev[1]); }
-        (void)hipEventRecord(g_ev[0], st);
-    }
+    if (e.variant == 4) use_v2 = false;
+#endif
+    const bool prof = ds != nullptr;
+    if (prof) (void)hipEventRecord(ds->prof[0], st);
     int rc;
-    if (use_v4_full) rc = launch_attn_v4_full(p, D, qk_fmt, is_causal, scale_mode, st);
-    else if (use_v3) rc = launch_attn_v3(p, D, qk_fmt, is_causal, scale_mode, st);
-    else rc = launch_attn_v2(p, D, qk_fmt, is_causal, scale_mode, st);
-    if (step_events) (void)hipEventRecord(g_ev[1], st);
+    if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
+    else rc = launch_attn_v4_full(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
+    if (prof) { (void)hipEventRecord(ds->prof[1], st); ds->recorded = true; }
     if (rc != QATTN_OK) return rc;
-    if ((p.dbg & 16) && p.dbg_buf) {  // diagnostic build path only: synchronises and prints per-wave sweep statistics
+#ifdef QATTN_DEV
+    if ((p.dbg & 16) && p.dbg_buf) {  // diagnostic path only: synchronises and prints per-wave sweep statistics
         static int printed = 0;
         (void)hipStreamSynchronize(st);
+        if (p.dbg & 64) {
+            const long rows = (long)a.B * a.Hq * a.Sq;
+            std::vector<float> r(rows * 4);
+            (void)hipMemcpy(r.data(), (const char*)p.dbg_buf + sizeof(unsigned long long) * (1 << 19), sizeof(float) * 4 * rows, hipMemcpyDeviceToHost);
+            std::vector<double> R;
+            for (long i = 0; i < rows; i++) { const float* d = &r[i * 4]; R.push_back(d[0] * exp2(-(5.0 + (d[1] - d[2]) * d[3]))); }
+            std::vector<double> Rs = R; std::sort(Rs.begin(), Rs.end());
+            fprintf(stderr, "[qattn dbg] R: min %.2f p1 %.2f med %.2f | row0: l %.1f m_true %.3f m_run %.3f c %.4e  row777: l %.1f m_true %.3f m_run %.3f\n", Rs[0], Rs[rows / 100], Rs[rows / 2],
+                    r[0], r[1], r[2], r[3], r[777 * 4], r[777 * 4 + 1], r[777 * 4 + 2]);
+        }
         if (printed++ == 3) {
             std::vector<unsigned long long> h(2 * n_dbg_waves);
             (void)hipMemcpy(h.data(), p.dbg_buf, sizeof(unsigned long long) * 2 * n_dbg_waves, hipMemcpyDeviceToHost);
@@ -109,7 +155,7 @@ static int attention_impl(const void* q8, const void* k8, const void* v8, void* 
             for (long i = 0; i < n_dbg_waves; i++) if (h[2 * i + 1]) { cyc.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
             if (!cyc.empty()) {
                 std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
-                const int iters = ceil_div(Skv, 64) + 2;
+                const int iters = ceil_div(a.Skv, 64) + 2;
                 if (p.dbg & 32) {
                     std::vector<unsigned long long> sg(64 * 8);
                     (void)hipMemcpy(sg.data(), p.dbg_buf + 2 * (1 << 19), sizeof(unsigned long long) * 64 * 8, hipMemcpyDeviceToHost);
@@ -117,17 +163,27 @@ static int attention_impl(const void* q8, const void* k8, const void* v8, void* 
                     for (int w = 0; w < 64; w++) for (int i = 0; i < 6; i++) tot[i] += (double)sg[w * 8 + i] / 64.0;
                     fprintf(stderr, "[qattn dbg] per-iteration segment cycles (mean of 64 waves): seg0 %.0f | seg1 %.0f | seg2 %.0f | seg3 %.0f | seg4 %.0f | seg5 %.0f\n",
                             tot[0] / iters, tot[1] / iters, tot[2] / iters, tot[3] / iters, tot[4] / iters, tot[5] / iters);
-                    for (int w = 0; w < 8; w++)
-                        fprintf(stderr, "[qattn dbg]   wave %d: %.0f %.0f %.0f %.0f %.0f %.0f\n", w, (double)sg[w * 8] / iters, (double)sg[w * 8 + 1] / iters,
-                                (double)sg[w * 8 + 2] / iters, (double)sg[w * 8 + 3] / iters, (double)sg[w * 8 + 4] / iters, (double)sg[w * 8 + 5] / iters);
                 }
                 fprintf(stderr, "[qattn dbg] waves=%zu sweep cycles median=%.0f (%.1f per iteration over %d) p10=%.0f p90=%.0f | in-kernel clock median %.3f GHz\n",
                         cyc.size(), cyc[cyc.size() / 2], cyc[cyc.size() / 2] / iters, iters, cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10], clk[clk.size() / 2]);
             }
         }
     }
+#endif
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
+
+// true when the attention kernel can quantise Q itself (hand-scheduled D = 128 kernel, head-wise scales, bf16 inputs,
+// byte-exponential path): then the pre-pass skips Q's payload (one read and one write of Q less).
+bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
+#ifdef QATTN_DEV
+    const DevEnv& e = dev_env();
+    if (e.variant != 2 || e.exact_exp || e.waves != 8 || e.no_q_fusion) return false;
+#endif
+    return D == 128 && in_fmt == QATTN_FMT_BF16 && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
+}
+
+}  // namespace
 
 extern "C" int qattn_abi_version(void) { return QATTN_ABI_VERSION; }
 
@@ -152,25 +208,50 @@ extern "C" int qattn_check_device(void) {
     return strstr(prop.gcnArchName, "gfx950") ? QATTN_OK : QATTN_ERR_DEVICE;
 }
 
+extern "C" void qattn_profile_attention(int enable) { t_profile = enable != 0; }
+
+extern "C" float qattn_last_attention_ms(void) {
+    DeviceState* ds = device_state(false);
+    if (!ds || !ds->recorded) return -1.0f;
+    float ms = 0.0f;
+    if (hipEventSynchronize(ds->prof[1]) != hipSuccess || hipEventElapsedTime(&ms, ds->prof[0], ds->prof[1]) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+extern "C" size_t qattn_attention_workspace_bytes(int B, int Hq, int Sq) {
+    if (B <= 0 || Hq <= 0 || Sq <= 0) return 0;
+    return sizeof(unsigned) * (size_t)B * Hq * ceil_div(Sq, 256);
+}
+
+extern "C" size_t qattn_lse_row_stride(int Sq, int lse_layout) {
+    if (Sq <= 0) return 0;
+    return lse_layout == QATTN_LSE_REFERENCE ? ((size_t)Sq * 4 + 15) / 16 * 16 / 4 : (size_t)Sq;  // tk/attention.py:439
+}
+
 extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, void* out, float* lse,
                                            const float* scale_q, const float* scale_k, const float* scale_v, int B,
                                            int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt,
-                                           int scale_mode, int is_causal, float sm_scale, void* stream) {
-    return attention_impl(q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt,
-                          scale_mode, is_causal, sm_scale, nullptr, nullptr, nullptr, 0, stream);
+                                           int scale_mode, int is_causal, float sm_scale, int precision, int lse_layout,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (B <= 0 || Hq <= 0 || Sq <= 0) return QATTN_ERR_INVALID_ARG;
+    const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
+    if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
+    AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
+               is_causal, sm_scale, precision, lse_layout, have_ws ? (unsigned*)workspace : nullptr, nullptr, nullptr, nullptr, 0};
+    DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
+    return attention_impl(a, (hipStream_t)stream, ds);
 }
 
-// true when the attention kernel can quantise Q itself (hand-scheduled D = 128 kernel, 8 waves, head-wise scales, bf16
-// inputs, byte-exponential path): then the pre-pass skips Q's payload (one read and one write of Q less).
-static bool q_fusion_ok(int D, int in_fmt, int scale_mode) {
-    return D == 128 && in_fmt == QATTN_FMT_BF16 && scale_mode == QATTN_SCALE_HEAD && kernel_variant() == 2 && !exact_exp() &&
-           env_int("QATTN_V2_WAVES", 8) == 8 && env_int("QATTN_NO_Q_FUSION", 0) == 0;
+extern "C" size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int Hkv, int Sq) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0) return 0;
+    // [abs-max bits of q, k, v | peaked-block flags of the attention call], the second part 16-byte aligned
+    return (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16 + qattn_attention_workspace_bytes(B, Hq, Sq);
 }
 
 extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
                                                  void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v, int B,
                                                  int Hq, int Hkv, int Sq, int Skv, int D, int fp8_fmt, int scale_mode,
-                                                 int numerics, int is_causal, float sm_scale, void* workspace,
+                                                 int numerics, int is_causal, float sm_scale, int precision, void* workspace,
                                                  size_t workspace_bytes, void* stream) {
     if (!q || !k || !v || !out || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
@@ -180,13 +261,20 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
     if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
     if (fp8_fmt != QATTN_FMT_E4M3 && fp8_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (!workspace || workspace_bytes < qattn_quant_qkv_workspace_bytes(B, Hq, Hkv)) return QATTN_ERR_WORKSPACE;
-    const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode);
+    if (!workspace || workspace_bytes < qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)) return QATTN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode, is_causal);
+    // (Tried and dropped, profiles/r02_overlap.md: running the HBM-bound pre-pass of batch group g+1 on a second stream beside
+    // the attention of group g.  The 512-thread attention workgroups leave 32-48 VGPRs per SIMD, the pre-pass waves displace
+    // them instead of sharing the CU, and the chip is power-limited on the attention kernel: the step got 19-31 % SLOWER.)
     unsigned* ws = (unsigned*)workspace;
+    unsigned* flags = (unsigned*)((unsigned char*)workspace + (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16);
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
-                              numerics, ws, fuse_q, (hipStream_t)stream);
+                              numerics, ws, fuse_q, st);
     if (rc != QATTN_OK) return rc;
-    return attention_impl(fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv,
-                          D, fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, fuse_q ? q : nullptr, fuse_q ? ws : nullptr,
-                          fuse_q ? scale_q : nullptr, numerics, stream);
+    AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
+               fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, flags,
+               fuse_q ? q : nullptr, fuse_q ? ws : nullptr, fuse_q ? scale_q : nullptr, numerics};
+    DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
+    return attention_impl(a, st, ds);
 }

@@ -11,8 +11,6 @@
 //   V16FRAG chunk = [t:2][m:D/32][s:2][hh:2][d:32][8 x 16 bit] piece j = V[64c + 32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]
 // so every 32-key tile (t) of K and of V is one linear LDS-DMA copy and every MFMA A operand is one conflict-free
 // ds_read_b128.  Exact exp2, fp32 row sums, deferred rescale; structure described at the kernel.
-#include <cstdlib>
-
 #include "qattn_attn.h"
 
 namespace qattn {
@@ -47,6 +45,7 @@ struct Attn16Params {
     int B, Hq, Hkv, Sq, Skv;
     int nqb, ntiles, xcd_remap;
     float sm_log2e;
+    int fast_exp;  // opt-in linear-mantissa exponential for rows that see >= kTwoTermKeys keys
 };
 
 constexpr int kWaves16 = 4;                        // 128 query rows per workgroup
@@ -61,8 +60,10 @@ constexpr int kStages16 = 2;
 // one v_fma_f32 per score + one v_cvt_pknorm_u16_f32 per pair, which already packs the PV B operand; relative error
 // 1.8 % rms, -3.9 .. +2.0 %), and the row sums of the SAME approximated weights come from two small
 // v_mfma_f32_16x16x32 per tile with a two-row selector A operand, so numerator and denominator stay consistent.  With the
-// exact path (v_exp_f32 + fp32 sums) the kernel is VALU-bound.  Used where a row sees >= kTwoTermKeys keys and no LSE
-// is requested; the exact instantiation covers the rest.
+// exact path (v_exp_f32 + fp32 sums) the kernel is VALU-bound.  FAST is OPT-IN (qattn_attention_forward_16's fast_exp
+// argument, config.attention.fast_exp16): its per-weight error only averages out over rows whose weight is spread over
+// many keys, so it is then used where a row sees >= kTwoTermKeys keys and no LSE is requested; the exact instantiation
+// (the reference's numerics: exact exp2, 16-bit P) is the default everywhere.
 constexpr float kFastExpBias = -0.0575f;  // centres the (1+f)/2^f mantissa error
 
 template <int D, int FMT16, bool CAUSAL, bool FAST>
@@ -343,11 +344,10 @@ static int launch16_one(const Attn16Params& p, int row_lo, int row_hi, hipStream
 
 template <int D, int FMT16>
 static int launch16(const Attn16Params& p, int causal, hipStream_t st) {
-    // rows that see fewer than kTwoTermKeys keys, and every row when an LSE output or exact exponentials are requested,
-    // take the exact instantiation
-    static const bool force_exact = getenv("QATTN_EXACT_EXP") && atoi(getenv("QATTN_EXACT_EXP")) != 0;
+    // the exact instantiation unless the caller opted into the fast exponential; even then rows that see fewer than
+    // kTwoTermKeys keys, and every row when an LSE output is requested, stay exact
     int rows_exact;
-    if (force_exact || p.lse != nullptr) rows_exact = p.Sq;
+    if (!p.fast_exp || p.lse != nullptr) rows_exact = p.Sq;
     else if (causal) rows_exact = min(p.Sq, ceil_div(min(kTwoTermKeys, p.Skv), kQPerWG16) * kQPerWG16);
     else rows_exact = p.Skv < kTwoTermKeys ? p.Sq : 0;
     int rc = QATTN_OK;
@@ -384,7 +384,8 @@ extern "C" int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H
 }
 
 extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, void* out, float* lse, int B, int Hq,
-                                          int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, void* stream) {
+                                          int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, int fast_exp,
+                                          void* stream) {
     if (!q || !k16 || !v16 || !out) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
@@ -399,6 +400,7 @@ extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const 
     p.xcd_remap = ((B * Hq) % 8 == 0) ? 1 : 0;
     const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
     p.sm_log2e = sm * 1.4426950408889634f;
+    p.fast_exp = fast_exp != 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (D == 64) rc = fmt == QATTN_FMT_BF16 ? launch16<64, QATTN_FMT_BF16>(p, is_causal, st) : launch16<64, QATTN_FMT_FP16>(p, is_causal, st);

@@ -19,12 +19,16 @@
 //  * the softmax exponentiates OPTIMISTICALLY against the running max m_run; only if some row's chunk max exceeds
 //    m_run by more than kRescaleThr (so P' could overflow e4m3) a rare fix-up branch rescales O and l and redoes the
 //    chunk's exponentials.  The common path has no branch between the MFMAs and the VALU work.
-//  * LDS ring of 3 stages, stage(t) = {K chunk t, V chunk t-2}, one s_barrier per iteration, DMA two iterations
-//    ahead behind a counted vmcnt.
-//  * P is scaled by 2^kPShift before the e4m3 conversion; where few keys are visible P is split hi+lo (two terms).
+//  * LDS ring of 2*kSyncEvery+1 = 5 slots, stage(t) = {K chunk t, V chunk t-1}, filled by LDS-DMA; the waves of a
+//    workgroup synchronise (vmcnt(0) + s_barrier) only every kSyncEvery = 2 iterations and then request the next two
+//    stages, so the two waves of a SIMD drift apart between barriers.
+//  * P is scaled by 2^kPShift before the e4m3 conversion.  One e4m3 term carries 3 mantissa bits, which is accurate enough
+//    only while a row's weight is spread over many keys, so:
+//      - query blocks that see fewer than kTwoTermKeys keys run with P split hi + lo (two terms, 2x the PV MFMAs);
+//      - every other block runs one term, tracks R = l / p_max (the inverse of the row's largest softmax weight) per row,
+//        and when a row ends with R < peak_r0 the whole 256-row block repeats its sweep in two-term mode before anything
+//        is stored.  Both paths live in one kernel, so a launch covers all query blocks of all heads.
 #include <type_traits>
-
-#include <cstdlib>
 
 #include "qattn_attn.h"
 
@@ -85,7 +89,8 @@ struct WaveState {
     v8i p[2];               // P^T (e4m3) ping-pong: p[t&1] holds chunk t
     v8i pl[TWO ? 2 : 1];    // low term of the two-term split (unused when !TWO)
     v8i vpre[2];            // V fragments (row blocks 0,1) of the NEXT iteration's PV, read one iteration ahead
-    float m_run;   // running max of the raw scores
+    float m_run;   // reference max of the raw scores: P' = 2^(shift + (s - m_run) c); updated only by the fix-up branch
+    float m_true;  // true running max (m_run <= m_true <= m_run + thr / c): gives the row's p_max for the peakedness test
     float l_run;   // this lane's partial row sum of P' (exact-exp mode)
     // BYTE mode: row sums of the quantised P', accumulated by ONE v_mfma_f32_16x16x128_f8f6f4 per chunk (32 cycles): its A
     // operand is 1.0 in row 0 for k-groups 0,2 and in row 1 for k-groups 1,3, so that with the P^T fragment as B (lane =
@@ -95,8 +100,10 @@ struct WaveState {
     v8i qreg[2];   // QREG kernels: the wave's Q^T fragments (both k-steps) held in registers instead of re-read from LDS
     v8i ones;      // BYTE mode: the all-ones A operand of that MFMA, kept opaque so it is not re-materialised every iteration
     float c;       // scale_q*scale_k*sm_scale*log2(e)
+#ifdef QATTN_DEV
     unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
     unsigned long long tlast;
+#endif
 };
 
 template <int QK_FMT, int D>
@@ -221,6 +228,9 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
 }
 
 #define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef QATTN_DEV
+#define QATTN2_STAMP(I) do { } while (0)
+#else
 #define QATTN2_STAMP(I)                                                                                          \
     do {                                                                                                        \
         if (ABL & 16) {                                                                                         \
@@ -232,6 +242,7 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
             st.tlast = t_;                                                                                      \
         }                                                                                                       \
     } while (0)
+#endif
 #define QATTN_SM_GROUP(FIRST, SX, J, MC, W, SEED)                                   \
     do {                                                                            \
         if (ABL & 4) break;                                                         \
@@ -338,6 +349,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
+    if (!TWO) st.m_true = fmaxf(st.m_true, mx);
     float ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     QATTN_SLOT_FENCE();
     QATTN2_STAMP(2);
@@ -452,8 +464,10 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+#ifdef QATTN_DEV
     for (int i = 0; i < 6; i++) st.seg[i] = 0;
     st.tlast = __builtin_amdgcn_s_memtime();
+#endif
     if (BYTE) {
         {   // A of the row-sum MFMA: lane = row (l & 15) + 16 * k-group; rows 0 / 1 are 1.0 (e4m3 0x38) on even / odd k-groups
             const int row = lane & 15, kg = lane >> 4;
@@ -511,29 +525,114 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     for (; t < T; ++t) sync_iter(t);
 }
 
-// QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
-// Q16: the fused step (qattn_fp8_quant_attention_forward): Q arrives as bf16 and is quantised here, row by row, with the
-// same quant8 sequence as the pre-pass (bit-identical q8), from the head's abs-max bits -- the pre-pass then neither
-// re-reads Q nor writes q8, and this kernel reads 2 instead of 1 byte per Q element once.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool Q16 = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p, const int qb_lo, const int qb_n) {
+// One pass of a wave over its KV range with P in TWO (hi + lo) or one term, BYTE-exponential or exact, followed by the
+// row sums.  Returns true when `check_peaked` is set and some row of the WORKGROUP turned out to be peaked (its largest
+// softmax weight 1 / R exceeds 1 / peak_r0): nothing has been stored then and the caller repeats the block in two-term
+// mode.  Otherwise the wave's 32 output rows (and the optional LSE) are stored.
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, typename LoadQ>
+__device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
+                                             const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
+                                             int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q) {
+    constexpr int MB = D / 32;
+    const int hh = lane >> 5;
+    WaveState<D, TWO, BYTE> st;
+#pragma unroll
+    for (int r = 0; r < 4; r++) st.lsum[r] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) st.o[m][r] = 0.0f;
+    st.m_run = -1.0e30f;  // finite sentinel: the first chunk always takes the fix-up branch
+    st.m_true = -1.0e30f;
+    st.l_run = 0.0f;
+    st.c = c;
+#ifdef QATTN_DEV
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // the Q^T rows travel to LDS while the first K/V stages do; QREG kernels then keep the fragments in registers
+    auto load_q_frags = [&]() {
+        load_q();
+        if (QREG) {
+            st.qreg[0] = lds_read_frag(qbuf);
+            st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
+        }
+    };
+    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags);
+#ifdef QATTN_DEV
+    if (p.dbg & 16) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            const long wid = (long)blockIdx.x * NW + wave;
+            p.dbg_buf[2 * wid] = t1 - dbg_t0;
+            p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
+            if ((ABL & 16) && wid < 64) {
+                unsigned long long* segout = p.dbg_buf + 2 * (1 << 19) + wid * 8;
+                for (int i = 0; i < 6; i++) segout[i] = st.seg[i];
+            }
+        }
+    }
+#endif
+    const float m_run = st.m_run, l_run = st.l_run;
+    v16f (&o)[MB] = st.o;
+
+    // ---- combine the two half-wave partial sums
+    float l_tot;
+    if (BYTE) {
+        // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
+        const float s0 = __shfl(st.lsum[0], threadIdx.x & 15), s1 = __shfl(st.lsum[1], threadIdx.x & 15);
+        l_tot = (threadIdx.x & 16) ? s1 : s0;
+    } else {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    constexpr float SHIFT = BYTE ? kPShiftByte : kPShift;
+    if (!TWO && check_peaked) {  // workgroup-uniform
+        // R = l' / p'_max with p'_max = 2^(shift + (m_true - m_run) c): the inverse of the row's largest softmax weight
+        const float r_inv_pmax = __builtin_amdgcn_exp2f(-(SHIFT + (st.m_true - m_run) * c));
+        const bool peaked = qrow < p.Sq && l_tot * r_inv_pmax < p.peak_r0;
+#ifdef QATTN_DEV
+        if ((p.dbg & 64) && p.dbg_buf && qrow < p.Sq && hh == 0) {
+            float* d = reinterpret_cast<float*>(p.dbg_buf + (1 << 19)) + (bh * p.Sq + qrow) * 4;
+            d[0] = l_tot; d[1] = st.m_true; d[2] = m_run; d[3] = c;
+        }
+#endif
+        if (__any(peaked) && lane == 0) *vote = 1u;
+        __syncthreads();
+        if (*vote != 0u) return true;
+    }
+
+    // ---- normalise, convert, store
+    const float sv = p.sv ? p.sv[kv_head] : 1.0f;
+    const float inv = sv / l_tot;
+    store_o_rows<MB>(p.out, p.out_fmt, o, inv, bh * p.Sq + qrow, hh, qrow < p.Sq);
+    if (qrow < p.Sq) {
+        if (p.lse && hh == 0) {
+            // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l'); QATTN_LSE_REFERENCE: the reference's (disabled) vector
+            // -(ln l + m ln2) sqrt(D) in rows padded to 16 bytes (tk/attention.py:333-346, 439-446)
+            const float lse = 0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot);
+            p.lse[bh * p.lse_stride + qrow] = lse * p.lse_mul;
+        }
+    }
+    return false;
+}
+
+// Everything a wave derives from its thread / block index for one pass over its query rows, and that pass itself (the Q^T
+// fragments are re-loaded by a second pass: a few KiB against the pass's megabytes of K / V).
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16>
+__device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* smem, int tid, bool check_peaked) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
     constexpr int KS = D / 64;      // QK^T k-steps
-    constexpr int MB = D / 32;      // O^T row blocks
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
 
-    // this launch covers query blocks [qb_lo, qb_lo + qb_n) of every head
     int head, qb;
-    map_block(p, blockIdx.x, qb_n, CAUSAL, head, qb);
-    qb += qb_lo;
+    map_block(p, blockIdx.x, p.nqb, CAUSAL, head, qb);
     const int b = head / p.Hq, h = head % p.Hq;
     const int hkv = h / (p.Hq / p.Hkv);
+    const long bh = (long)b * p.Hq + h;
     const long kv_head = (long)b * p.Hkv + hkv;
     constexpr int QWG = NW * kQPerWave;
     const int q0_wg = qb * QWG;
@@ -547,44 +646,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + QWG, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
 
-
     // Q^T fragments: global -> this lane's own slots of the workgroup's Q area in LDS (behind the K/V ring);
     // only the writing lane ever reads them back, so no barrier is needed (the compiler orders the lane's own
-    // ds_write -> ds_read with lgkmcnt).
+    // ds_write -> ds_read with lgkmcnt).  One word behind the Q area collects the workgroup's "a row is peaked" vote.
     unsigned char* qbuf = smem + kStagesV2 * STAGE + wave * (KS << 11) + (hh << 10) + (ql << 4);
+    unsigned* vote = reinterpret_cast<unsigned*>(smem + kStagesV2 * STAGE + NW * kQPerWave * D);
     float scale_q16 = 1.0f;
     if (Q16) {
         static_assert(!Q16 || !TOKEN, "the fused Q path is head-wise");
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(p.q_amax_bits[(long)b * p.Hq + h]), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
-        if (q0_wg == 0 && tid == 0) p.sq_out[(long)b * p.Hq + h] = scale_q16;
+        scale_q16 = make_scale(__uint_as_float(p.q_amax_bits[bh]), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
     }
     // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210)
     float c;
-    if (TOKEN) c = p.sm_log2e * (qrow < p.Sq ? p.sq[((long)b * p.Hq + h) * p.Sq + qrow] : 1.0f);
+    if (TOKEN) c = p.sm_log2e * (qrow < p.Sq ? p.sq[bh * p.Sq + qrow] : 1.0f);
     else if (Q16) c = p.sm_log2e * scale_q16 * p.sk[kv_head];
-    else c = p.sm_log2e * p.sq[(long)b * p.Hq + h] * p.sk[kv_head];
+    else c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
     const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
 
-    WaveState<D, TWO, BYTE> st;
-#pragma unroll
-    for (int r = 0; r < 4; r++) st.lsum[r] = 0.0f;
-#pragma unroll
-    for (int m = 0; m < MB; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) st.o[m][r] = 0.0f;
-    st.m_run = -1.0e30f;  // finite sentinel: the first chunk always takes the fix-up branch
-    st.l_run = 0.0f;
-    st.c = c;
-    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
-    if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
-    constexpr bool QREG = BYTE && !TWO && !(ABL & 128);  // one-term byte kernel: 16 registers to spare for the Q^T fragments
     // invoked by kv_sweep right after the first K/V stages have been requested, so the two latencies overlap
     auto load_q = [&]() {
         const bool qvalid = qrow < p.Sq;
         if (Q16) {
             const float rinv = 1.0f / scale_q16;
-            const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
+            const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
             uint4 raw[KS][4];
 #pragma unroll
             for (int s = 0; s < KS; s++)
@@ -602,7 +688,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
                 *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = v4i{w[2].x, w[2].y, w[3].x, w[3].y};
             }
         } else {
-            const unsigned char* qp = p.q + (((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32;
+            const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? qrow : 0)) * D) + hh * 32;
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 v4i lo = *reinterpret_cast<const v4i*>(qp + s * 64);
@@ -612,102 +698,74 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
                 *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = hi;
             }
         }
-        if (QREG) {
-            st.qreg[0] = lds_read_frag(qbuf);
-            st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
-        }
     };
-    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q);
-    if (p.dbg & 16) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            const long wid = (long)blockIdx.x * NW + wave;
-            p.dbg_buf[2 * wid] = t1 - dbg_t0;
-            p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
-            if ((ABL & 16) && wid < 64) {
-                unsigned long long* segout = p.dbg_buf + 2 * (1 << 19) + wid * 8;
-                for (int i = 0; i < 6; i++) segout[i] = st.seg[i];
-            }
-        }
-    }
-    const float m_run = st.m_run, l_run = st.l_run;
-    v16f (&o)[MB] = st.o;
+    // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
+    constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
+    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(
+        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q);
+}
 
-    // ---- epilogue: combine the two half-wave partial sums, normalise, convert, store
-    float l_tot;
-    if (BYTE) {
-        // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
-        const float s0 = __shfl(st.lsum[0], threadIdx.x & 15), s1 = __shfl(st.lsum[1], threadIdx.x & 15);
-        l_tot = (threadIdx.x & 16) ? s1 : s0;
-    } else {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-        l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const float sv = p.sv ? p.sv[kv_head] : 1.0f;
-    const float inv = sv / l_tot;
-    if (qrow < p.Sq) {
-        const long row_off = (((long)b * p.Hq + h) * p.Sq + qrow) * D;
-        if (p.out_fmt == QATTN_FMT_BF16) {
-            __bf16* op = reinterpret_cast<__bf16*>(p.out) + row_off;
-#pragma unroll
-            for (int m = 0; m < MB; m++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-                    bf4 t;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) t[i] = (__bf16)(o[m][4 * j + i] * inv);
-                    *reinterpret_cast<bf4*>(op + 32 * m + 8 * j + 4 * hh) = t;
-                }
-        } else {
-            _Float16* op = reinterpret_cast<_Float16*>(p.out) + row_off;
-#pragma unroll
-            for (int m = 0; m < MB; m++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    h4 t;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) t[i] = (_Float16)(o[m][4 * j + i] * inv);
-                    *reinterpret_cast<h4*>(op + 32 * m + 8 * j + 4 * hh) = t;
-                }
+// QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
+// BYTE: the one-term pass uses the byte exponential (else exact v_exp_f32 + RNE conversion, needed for the LSE output).
+// Q16: the fused step (qattn_fp8_quant_attention_forward): Q arrives as bf16 and is quantised here, row by row, with the
+// same quant8 sequence as the pre-pass (bit-identical q8), from the head's abs-max bits -- the pre-pass then neither
+// re-reads Q nor writes q8, and this kernel reads 2 instead of 1 byte per Q element once.
+// One launch covers every query block of every head: blocks qb < p.n_two go straight to the two-term pass.
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int VOTE_OFF = kStagesV2 * 2 * 64 * D + NW * kQPerWave * D;
+    if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(smem + VOTE_OFF) = 0u;  // ordered before any vote by the barriers of the sweep
+    int head, qb;
+    map_block(p, blockIdx.x, p.nqb, CAUSAL, head, qb);
+    // One copy of each pass: a peaked block loops back into the two-term code that the blocks qb < n_two enter directly.
+    // Every per-lane value is re-derived inside block_pass from an opaque copy of the thread index, so nothing of the
+    // one-term pass stays live in registers across the two-term loop (and vice versa).
+    bool two = qb < p.n_two;  // workgroup-uniform
+    int tid = threadIdx.x;
+    for (;;) {
+        asm volatile("" : "+v"(tid));
+        if (two) {
+            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, false);
+            return;
         }
-        if (p.lse && hh == 0) {
-            // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l')
-            p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = 0.6931471805599453f * (m_run * c - (BYTE ? kPShiftByte : kPShift)) + __logf(l_tot);
-        }
+        if (!block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, p.peak_r0 > 0.0f)) return;
+        two = true;  // a row of this block is peaked: every wave is past the vote barrier, hence done with the K/V ring
     }
 }
 
-template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, bool Q16 = false>
-static int launch_attn_v2_one(const AttnParams& p, int qb_lo, int qb_n, hipStream_t st) {
-    if (qb_n <= 0) return QATTN_OK;
-    const int grid = p.B * p.Hq * qb_n;
-    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D;  // K/V ring + parked Q^T fragments
+template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16 = false>
+static int launch_attn_v2_one(const AttnParams& p, hipStream_t st) {
+    const int grid = p.B * p.Hq * p.nqb;
+    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 16;  // K/V ring + parked Q^T fragments + vote word
+#ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
-    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, TWO, BYTE, 0, Q16>;
+#endif
+    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 0, Q16>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
     return QATTN_OK;
 }
 
-// Query blocks whose first row sees fewer than kTwoTermKeys keys run the two-term (hi+lo fp8 P) instantiation,
-// the rest the one-term one: two launches over disjoint q-block ranges of the same output tensor.
 template <int D, int NW, int FMT, bool CAUSAL>
-static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st) {
-    int n_two;  // leading q-blocks that need two-term P
-    static const int two_keys = getenv("QATTN_TWO_TERM_KEYS") ? atoi(getenv("QATTN_TWO_TERM_KEYS")) : kTwoTermKeys;  // development switch
-    if (CAUSAL) n_two = min(p.nqb, ceil_div(min(two_keys, p.Skv), NW * kQPerWave));
-    else n_two = p.Skv < two_keys ? p.nqb : 0;
+static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t st) {
+    AttnParams p = pin;
+    // leading query blocks that run two-term P from the start: every block (QATTN_PRECISION_ACCURATE), or the blocks whose
+    // first row sees fewer than kTwoTermKeys keys -- there even a flat row averages over too few keys
+    if (p.precision == QATTN_PRECISION_ACCURATE) p.n_two = p.nqb;
+    else if (CAUSAL) p.n_two = min(p.nqb, ceil_div(min(p.two_term_keys, p.Skv), NW * kQPerWave));
+    else p.n_two = p.Skv < p.two_term_keys ? p.nqb : 0;
+#ifdef QATTN_DEV
     if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
         const int grid = p.B * p.Hq * p.nqb;
-        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D;
+        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 16;
+        p.n_two = 0; p.peak_r0 = 0.0f;
 #define QATTN_ABL_CASE(M)                                                                                          \
         case M: {                                                                                                  \
-            auto kern = attn_fwd_kernel_v2<D, 8, QATTN_FMT_E4M3, QATTN_FMT_E4M3, false, false, false, true, M>;    \
+            auto kern = attn_fwd_kernel_v2<D, 8, QATTN_FMT_E4M3, QATTN_FMT_E4M3, false, false, true, M>;           \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, 0, p.nqb);                             \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);                                       \
             return QATTN_OK;                                                                                       \
         }
         switch ((p.dbg & 15) | ((p.dbg & 32) ? 16 : 0) | ((p.dbg & 64) ? 32 : 0) | ((p.dbg & 128) ? 64 : 0)) {
@@ -717,25 +775,15 @@ static int launch_attn_v2_t(const AttnParams& p, int scale_mode, hipStream_t st)
         }
 #undef QATTN_ABL_CASE
     }
-    // byte-exponential fast path for the one-term launch, unless the caller wants the LSE (needs the exact row sum)
-    // or exact exponentials were requested (QATTN_EXACT_EXP=1)
-    const bool byte_exp = !p.exact_exp && p.lse == nullptr;
-    int rc;
-    if (scale_mode == QATTN_SCALE_TOKEN) {
-        if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, true>(p, n_two, p.nqb - n_two, st);
-        else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, false, false>(p, n_two, p.nqb - n_two, st);
-        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, true, true, false>(p, 0, n_two, st);
-    } else if (p.q16 != nullptr) {
-        // fused step: the API only takes this route for NW == 8, byte-exponential, head-wise (qattn_api.hip)
-        rc = launch_attn_v2_one<D, 8, FMT, CAUSAL, false, false, true, true>(p, n_two, p.nqb - n_two, st);
-        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, 8, FMT, CAUSAL, false, true, false, true>(p, 0, n_two, st);
-    } else {
-        if (byte_exp && p.use_v4 && D == 128) rc = launch_attn_v4(p, 128, FMT, CAUSAL, scale_mode, n_two * NW * kQPerWave, st);
-        else if (byte_exp) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, true>(p, n_two, p.nqb - n_two, st);
-        else rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false, false>(p, n_two, p.nqb - n_two, st);
-        if (rc == QATTN_OK) rc = launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true, false>(p, 0, n_two, st);
-    }
-    return rc;
+#endif
+    // byte-exponential one-term pass, unless the caller wants the LSE (needs the exact row sum) or exact exponentials
+    bool byte_exp = !p.exact_exp && p.lse == nullptr;
+#ifdef QATTN_DEV
+    if (p.lds_pad == -1) byte_exp = true;  // debugging: LSE from the byte-exponential pass (QATTN_V2_LDS=-1)
+#endif
+    if (scale_mode == QATTN_SCALE_TOKEN) return QATTN_ERR_UNSUPPORTED_FMT;  // routed to the templated kernel (attn_v2_covers)
+    if (p.q16 != nullptr) return launch_attn_v2_one<D, 8, FMT, CAUSAL, false, true, true>(p, st);  // fused step: byte path only (qattn_api.hip)
+    return byte_exp ? launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true>(p, st) : launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false>(p, st);
 }
 
 template <int D, int NW>
@@ -744,9 +792,19 @@ static int launch_attn_v2_d(const AttnParams& p, int fmt, int causal, int scale_
     return causal ? launch_attn_v2_t<D, NW, QATTN_FMT_E5M2, true>(p, scale_mode, st) : launch_attn_v2_t<D, NW, QATTN_FMT_E5M2, false>(p, scale_mode, st);
 }
 
+// true when this file's hand-scheduled kernel covers the case: D = 128 with head-wise scales.  Token-wise scales need 32
+// more registers per chunk for the per-key factors, which does not fit 256 registers at two waves per SIMD next to the
+// two-term pass: those calls run on the templated kernel (qattn_attn_v4.hip).
+bool attn_v2_covers(int D, int causal, int scale_mode) {
+    (void)causal;
+    return D == 128 && scale_mode == QATTN_SCALE_HEAD;
+}
+
 int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (D != 128) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (!attn_v2_covers(D, causal, scale_mode)) return QATTN_ERR_UNSUPPORTED_DIM;
+#ifdef QATTN_DEV
     if (p.waves == 4) return launch_attn_v2_d<128, 4>(p, fmt, causal, scale_mode, st);
+#endif
     return launch_attn_v2_d<128, 8>(p, fmt, causal, scale_mode, st);
 }
 

@@ -8,7 +8,10 @@
 // with single-buffered S and P (<= 168 registers), a workgroup is 4 waves x 32 rows with a two-stage K/V ring
 // (48 KiB LDS), and a CU holds THREE independent workgroups: each SIMD interleaves three waves that belong to different
 // workgroups, hence are never phase-aligned, and one wave's softmax hides under the other two's MFMAs.
-// Used for the one-term byte-exponential case (no LSE output); two-term blocks and exact exponentials stay on v2.
+// Templated on the head dimension: the whole forward for D = 64 / 256 and the D = 128 cases the hand-scheduled kernel does
+// not cover (token-wise scales under the causal mask).  Precision modes: the one-term launch records,
+// per (head, 256-row block), whether a row ended peaked (R = l / p_max < peak_r0) in p.flags; a second launch of the exact
+// two-term variant over the same blocks recomputes exactly the flagged ones (unflagged workgroups return at once).
 #include "qattn_attn.h"
 
 namespace qattn {
@@ -37,7 +40,9 @@ __device__ __forceinline__ int byte_exp4(float s0, float s1, float s2, float s3,
 // (LSE output), and -- when `two` is set for the launch -- the hi+lo two-term P for rows that see few keys.
 template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE>
 __global__ __launch_bounds__((V4Shape<D, (BYTE && !TOKEN)>::NW * 64), (V4Shape<D, (BYTE && !TOKEN)>::WPS))
-void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, const int two) {
+void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, const int mode) {
+    const int two = mode & 1;            // exact kernels: hi + lo (two-term) P
+    const bool only_flagged = mode & 2;  // rescue launch: recompute only the blocks the one-term launch flagged
     constexpr int NW = V4Shape<D, (BYTE && !TOKEN)>::NW, kQPerWG4 = NW * kQPerWave;
     constexpr int CH = 64 * D, STAGE = 2 * CH, MB = D / 32, KS = D / 64;
     constexpr int RK = CH / (NW * 1024);   // 1 KiB DMA pieces per wave for the K (and for the V) part of a stage
@@ -52,6 +57,9 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     const int b = head / p.Hq, h = head % p.Hq;
     const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
     const int q0_wg = qb * kQPerWG4, q0 = q0_wg + wave * kQPerWave, qrow = q0 + ql;
+    const long bh = (long)b * p.Hq + h;
+    unsigned* flag = p.flags ? p.flags + bh * ((p.Sq + 255) >> 8) + (q0_wg >> 8) : nullptr;
+    if (only_flagged && *flag == 0u) return;  // workgroup-uniform
     const unsigned char* kg_w = p.k + kv_head * (long)p.nchunks * CH + (wave << 10);
     const unsigned char* vg_w = p.v + kv_head * (long)p.nchunks * CH + (wave << 10);
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + kQPerWG4, p.Sq) - 1) / 64 + 1) : p.nchunks;
@@ -106,12 +114,10 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
 #pragma unroll
         for (int w = 0; w < 8; w++) ones[w] = one;
     }
-    float m_run = -1.0e30f, l_run = 0.0f;
+    float m_run = -1.0e30f, m_true = -1.0e30f, l_run = 0.0f;
     constexpr float U16 = 1.0f / 65535.0f;
     const float c8 = (8.0f * U16) * c;
     const int frag_lane_off = (hh << 10) + (ql << 4);
-    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
-    if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     for (int t = 0; t < n_wg; t++) {
         // Q^T fragments do not depend on the stage: request them before the barrier so their LDS latency hides behind it
@@ -172,6 +178,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
             auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
+        m_true = fmaxf(m_true, mx);
         if (__builtin_expect(__any((mx - m_run) * c > kRescaleThrByte) != 0, 0)) {
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -240,14 +247,6 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
         }
         if (BYTE) lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
     }
-    if (p.dbg & 16) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            const long wid = (long)blockIdx.x * NW + wave;
-            p.dbg_buf[2 * wid] = t1 - dbg_t0;
-            p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
-        }
-    }
 
     // ---- epilogue
     float l_tot;
@@ -258,42 +257,21 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
+    constexpr float SHIFT = BYTE ? kPShiftByte : kPShift;
+    if (p.peak_r0 > 0.0f && !two && !only_flagged) {
+        // one-term launch: R = l' / p'_max is the inverse of the row's largest softmax weight; a peaked row flags its block
+        const bool peaked = qrow < p.Sq && l_tot * __builtin_amdgcn_exp2f(-(SHIFT + (m_true - m_run) * c)) < p.peak_r0;
+        if (__any(peaked) && lane == 0) *flag = 1u;
+    }
     const float sv = p.sv ? p.sv[kv_head] : 1.0f;
     const float inv = sv / l_tot;
-    if (qrow < p.Sq) {
-        const long row_off = (((long)b * p.Hq + h) * p.Sq + qrow) * D;
-        if (p.out_fmt == QATTN_FMT_BF16) {
-            __bf16* op = reinterpret_cast<__bf16*>(p.out) + row_off;
-#pragma unroll
-            for (int m = 0; m < MB; m++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-                    bf4 tv;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) tv[i] = (__bf16)(o[m][4 * j + i] * inv);
-                    *reinterpret_cast<bf4*>(op + 32 * m + 8 * j + 4 * hh) = tv;
-                }
-        } else {
-            _Float16* op = reinterpret_cast<_Float16*>(p.out) + row_off;
-#pragma unroll
-            for (int m = 0; m < MB; m++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    h4 tv;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) tv[i] = (_Float16)(o[m][4 * j + i] * inv);
-                    *reinterpret_cast<h4*>(op + 32 * m + 8 * j + 4 * hh) = tv;
-                }
-        }
-        if (!BYTE && p.lse && hh == 0)  // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l')
-            p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = 0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot);
-    }
+    store_o_rows<MB>(p.out, p.out_fmt, o, inv, bh * p.Sq + qrow, hh, qrow < p.Sq);
+    if (!BYTE && p.lse && hh == 0 && qrow < p.Sq)  // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l')
+        p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
 }
 
 template <int D, int FMT, bool CAUSAL, bool TOKEN, bool BYTE>
-static int launch_v4_one(const AttnParams& p, int row_lo, int row_hi, int two, hipStream_t st) {
+static int launch_v4_one(const AttnParams& p, int row_lo, int row_hi, int mode, hipStream_t st) {
     constexpr int NW = V4Shape<D, (BYTE && !TOKEN)>::NW, ROWS = NW * kQPerWave;
     const int qb_lo = row_lo / ROWS, qb_n = ceil_div(min(row_hi, p.Sq), ROWS) - qb_lo;
     if (qb_n <= 0) return QATTN_OK;
@@ -301,14 +279,14 @@ static int launch_v4_one(const AttnParams& p, int row_lo, int row_hi, int two, h
     const size_t lds = (size_t)kStages4 * 2 * 64 * D + (size_t)NW * kQPerWave * D;  // K/V ring + parked Q^T fragments
     auto kern = attn_fwd_kernel_v4<D, FMT, FMT, CAUSAL, TOKEN, BYTE>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n, two);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n, mode);
     return QATTN_OK;
 }
 
 template <int D, bool BYTE>
-static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, int row_hi, int two, hipStream_t st) {
+static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, int row_hi, int mode, hipStream_t st) {
     const bool tok = scale_mode == QATTN_SCALE_TOKEN;
-#define QATTN_V4(F, C, T) return launch_v4_one<D, F, C, T, BYTE>(p, row_lo, row_hi, two, st)
+#define QATTN_V4(F, C, T) return launch_v4_one<D, F, C, T, BYTE>(p, row_lo, row_hi, mode, st)
     if (fmt == QATTN_FMT_E4M3) {
         if (causal) { if (tok) QATTN_V4(QATTN_FMT_E4M3, true, true); else QATTN_V4(QATTN_FMT_E4M3, true, false); }
         else { if (tok) QATTN_V4(QATTN_FMT_E4M3, false, true); else QATTN_V4(QATTN_FMT_E4M3, false, false); }
@@ -319,34 +297,36 @@ static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode,
 #undef QATTN_V4
 }
 
-// Rows [row_lo, Sq) of every head on the byte-exponential v4 kernel (row_lo a multiple of 256).  No LSE.
-int launch_attn_v4(const AttnParams& p, int D, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
-    if (D == 64) return launch_v4_d<64, true>(p, fmt, causal, scale_mode, row_lo, p.Sq, 0, st);
-    if (D == 128) return launch_v4_d<128, true>(p, fmt, causal, scale_mode, row_lo, p.Sq, 0, st);
-    return launch_v4_d<256, true>(p, fmt, causal, scale_mode, row_lo, p.Sq, 0, st);
+template <int D>
+static int launch_v4_full_d(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) {
+    // leading rows (a multiple of 256) that run two-term P from the start: all of them (QATTN_PRECISION_ACCURATE) or those
+    // that see fewer than kTwoTermKeys keys
+    const int rows_all = ceil_div(p.Sq, 256) * 256;
+    int rows_two;
+    if (p.precision == QATTN_PRECISION_ACCURATE) rows_two = rows_all;
+    else if (causal) rows_two = min(rows_all, ceil_div(min(p.two_term_keys, p.Skv), 256) * 256);
+    else rows_two = p.Skv < p.two_term_keys ? rows_all : 0;
+    const bool byte_exp = !p.exact_exp && p.lse == nullptr;
+    const bool rescue = p.peak_r0 > 0.0f && rows_two < p.Sq;
+    if (rescue) {
+        if (!p.flags) return QATTN_ERR_WORKSPACE;
+        if (hipMemsetAsync(p.flags, 0, sizeof(unsigned) * (size_t)p.B * p.Hq * ceil_div(p.Sq, 256), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+    }
+    int rc = QATTN_OK;
+    if (rows_two < p.Sq)
+        rc = byte_exp ? launch_v4_d<D, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
+                      : launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
+    if (rc == QATTN_OK && rows_two > 0) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, 0, rows_two, 1, st);
+    if (rc == QATTN_OK && rescue) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 3, st);
+    return rc;
 }
 
-// The whole forward for D = 64 / 256 (the hand-scheduled v2 kernel exists for D = 128 only): rows that see fewer than
-// kTwoTermKeys keys run the exact two-term variant, the rest the byte-exponential one (or the exact one-term variant when
-// an LSE output or exact exponentials are requested).
+// The whole forward on the templated kernel: D = 64 / 256, and D = 128 where qattn_attn_v2.hip does not apply.
 int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (D != 64 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
-    int rows_two;  // leading rows (a multiple of 256) that need the two-term P
-    if (causal) rows_two = min(ceil_div(p.Sq, 256), ceil_div(min(kTwoTermKeys, p.Skv), 256)) * 256;
-    else rows_two = p.Skv < kTwoTermKeys ? ceil_div(p.Sq, 256) * 256 : 0;
-    const bool byte_exp = !p.exact_exp && p.lse == nullptr;
-    int rc = QATTN_OK;
-    if (rows_two < p.Sq) {
-        if (D == 64) rc = byte_exp ? launch_v4_d<64, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
-                                   : launch_v4_d<64, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
-        else rc = byte_exp ? launch_v4_d<256, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
-                           : launch_v4_d<256, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
-    }
-    if (rc == QATTN_OK && rows_two > 0) {
-        if (D == 64) rc = launch_v4_d<64, false>(p, fmt, causal, scale_mode, 0, rows_two, 1, st);
-        else rc = launch_v4_d<256, false>(p, fmt, causal, scale_mode, 0, rows_two, 1, st);
-    }
-    return rc;
+    if (D == 64) return launch_v4_full_d<64>(p, fmt, causal, scale_mode, st);
+    if (D == 128) return launch_v4_full_d<128>(p, fmt, causal, scale_mode, st);
+    if (D == 256) return launch_v4_full_d<256>(p, fmt, causal, scale_mode, st);
+    return QATTN_ERR_UNSUPPORTED_DIM;
 }
 
 }  // namespace qattn

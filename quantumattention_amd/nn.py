@@ -2,8 +2,12 @@
 (bool, reason), `fp8_attention` (nn.py:433-539) raising ValueError(reason) on unsupported input, `attention`
 (nn.py:325-391), `dynamically_quantize_fp8` (nn.py:22-42).  The reference wraps the call in torch.compile so that
 Inductor can swap in its kernel; here the custom ops call the gfx950 kernels directly, so no compilation happens
-on the hot path (calls from inside a user's torch.compile region trace the ops as opaque extern calls)."""
-from typing import Optional, Tuple, Union
+on the hot path (calls from inside a user's torch.compile region trace the ops as opaque extern calls).
+
+`config.attention.force_eager_fallback` keeps the reference's meaning (nn.py:367-371, 503-516): skip the kernel and run
+the op's eager *definition* (eager quantiser, de-quantise, aten SDPA -- ops.py:64-95) with torch ops on the tensors'
+device.  It is a debugging switch the caller sets explicitly; nothing selects it silently."""
+from typing import Callable, List, Optional, Tuple, Union
 
 import torch
 from torch import Tensor
@@ -11,9 +15,9 @@ from torch import Tensor
 from . import config
 from .utils import checks
 
-_HIP_SUPPORTED_HEAD_DIMS = [64, 128, 256]  # nn.py:45
-_HIP_16BIT_HEAD_DIMS = [64, 128, 256]  # same set as the fp8 path (nn.py:45)
+_HIP_SUPPORTED_HEAD_DIMS = [64, 128, 256]  # nn.py:45; the 16-bit sibling path covers the same set
 _FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
+_HALF_DTYPES = (torch.float16, torch.bfloat16)
 
 
 def _ops():
@@ -26,72 +30,162 @@ def _hip_supported_head_dim(n: Union[int, torch.SymInt]) -> bool:
     return n in _HIP_SUPPORTED_HEAD_DIMS
 
 
+class _Call:
+    """The arguments of one attention call, as the validation rules see them."""
+
+    __slots__ = ("q", "k", "v", "attn_mask", "dropout_p", "scale", "scaling_method", "scale_q", "scale_k")
+
+    def __init__(self, q, k, v, attn_mask, dropout_p, scale, scaling_method, scale_q=None, scale_k=None):
+        self.q, self.k, self.v = q, k, v
+        self.attn_mask, self.dropout_p, self.scale = attn_mask, dropout_p, scale
+        self.scaling_method, self.scale_q, self.scale_k = scaling_method, scale_q, scale_k
+
+
+# Each rule returns None (passes) or the reason string.  The reasons are interface contract: they are the strings
+# `can_use_attention` hands back in the reference (nn.py:52-124) wherever the same condition exists there; rules the
+# reference's C++ launcher enforces instead (batch / head_dim agreement, tk/attention.py:385-415) are added at the end.
+def _r_leaf(c):
+    if any(t.requires_grad for t in (c.q, c.k, c.v)):
+        return "NYI: query, key, and value must be leaf tensors"
+
+
+def _r_mask(c):
+    if c.attn_mask is not None:
+        return "NYI: attn_mask must be None"
+
+
+def _r_dropout(c):
+    if c.dropout_p != 0.0:
+        return "NYI: dropout_p must be 0.0"
+
+
+def _r_scale(c):
+    if c.scale is not None:
+        return "NYI: scale must be None"
+
+
+def _r_method(c):
+    if c.scaling_method is not None and c.scaling_method not in ("head-wise", "token-wise"):
+        return f"Unsupported scaling_method: {c.scaling_method}"
+
+
+def _r_query_dtype(c):
+    if c.scaling_method is None:
+        if c.q.dtype not in _HALF_DTYPES:
+            return f"Expected query to have dtype torch.float16 or torch.bfloat16, but got query.dtype: {c.q.dtype} instead."
+        if c.q.dtype != c.v.dtype:
+            return (f"Expected query and value to have the same dtype, but got query.dtype: {c.q.dtype}, "
+                    f"value.dtype: {c.v.dtype} instead.")
+    elif c.q.dtype not in _HALF_DTYPES + _FP8_DTYPES:
+        return ("Expected query to have dtype torch.float16, torch.bfloat16, or torch.float8_e4m3fn, "
+                f"but got query.dtype: {c.q.dtype} instead.")
+
+
+def _r_key_dtype(c):
+    if c.q.dtype != c.k.dtype:
+        return (f"Expected query and key to have the same dtype, but got query.dtype: {c.q.dtype}, "
+                f"key.dtype: {c.k.dtype} instead.")
+
+
+def _r_value_dtype(c):
+    if c.v.dtype not in _HALF_DTYPES:
+        return f"Expected value to have dtype torch.float16 or torch.bfloat16, but got value.dtype: {c.v.dtype} instead."
+
+
+def _r_same_device(c):
+    if c.q.device != c.k.device or c.q.device != c.v.device:
+        return ("Expected query, key, and value to have the same device type, but got "
+                f"query.device: {c.q.device}, key.device: {c.k.device}, and value.device: {c.v.device} instead.")
+
+
+def _r_cuda(c):
+    if c.q.device.type != "cuda":
+        return "Expected query, key, and value to be on a CUDA device"
+
+
+def _r_rank(c):
+    if c.q.dim() != 4 or c.k.dim() != 4 or c.v.dim() != 4:
+        return "NYI: query, key, and value must be 4D tensors"
+
+
+def _r_kv_len(c):
+    if c.k.size(-2) != c.v.size(-2):
+        return f"Expect key and value to have the same sequence length but got Sk={c.k.size(-2)} and Sv={c.v.size(-2)}."
+
+
+def _r_embed(c):
+    if c.v.size(-1) != c.q.size(-1):
+        return "NYI: query and value must have the same embedding dimension"
+
+
+def _r_heads(c):  # GQA is accepted here (the reference requires Hq == Hkv at this level, nn.py:113-117)
+    if c.k.size(-3) != c.v.size(-3) or c.q.size(-3) % c.k.size(-3) != 0:
+        return ("Expect the number of query heads to be a multiple of the key/value heads but got "
+                f"Hq={c.q.size(-3)} and Hkv={c.k.size(-3)}.")
+
+
+def _r_head_dim(c):
+    if not _hip_supported_head_dim(c.q.size(-1)):
+        return f"Unsupported head dimension: {c.q.size(-1)}"
+
+
+def _r_key_embed(c):  # tk/attention.py:394-396
+    if c.k.size(-1) != c.q.size(-1):
+        return (f"Expect query and key to have the same embedding dimension but got Dq={c.q.size(-1)} "
+                f"and Dk={c.k.size(-1)}.")
+
+
+def _r_batch(c):  # tk/attention.py:385-388
+    if c.k.size(0) != c.q.size(0) or c.v.size(0) != c.q.size(0):
+        return (f"Expect query, key, and value to have the same batch size but got Bq={c.q.size(0)}, "
+                f"Bk={c.k.size(0)} and Bv={c.v.size(0)}.")
+
+
+def _r_scales(c):  # tk/attention.py:402-414, extended to the token-wise shape [B,H,S]
+    if (c.scale_q is None) != (c.scale_k is None):
+        return "scale_q and scale_k must be both provided or both not provided"
+    if c.scale_q is None:
+        if c.q.dtype in _FP8_DTYPES:
+            return "fp8 query and key need scale_q and scale_k"
+        return None
+    if c.q.dtype not in _FP8_DTYPES:
+        return f"scale_q and scale_k are only accepted with fp8 query and key, but got query.dtype: {c.q.dtype}."
+    return scale_shapes_reason(c.q, c.k, c.scale_q, c.scale_k)
+
+
+_RULES: List[Callable[[_Call], Optional[str]]] = [
+    _r_leaf, _r_mask, _r_dropout, _r_scale, _r_method, _r_query_dtype, _r_key_dtype, _r_value_dtype, _r_same_device,
+    _r_cuda, _r_rank, _r_kv_len, _r_embed, _r_heads, _r_head_dim, _r_key_embed, _r_batch, _r_scales,
+]
+
+
+def scale_shapes_reason(query, key, scale_q, scale_k) -> Optional[str]:
+    """fp32, same device, and exactly [B,H] (head-wise) or [B,H,S] (token-wise) for both scales -- else the reason."""
+    for name, s, t in (("scale_q", scale_q, query), ("scale_k", scale_k, key)):
+        if s.dtype != torch.float32:
+            return f"Expected {name} to have dtype torch.float32, but got {s.dtype} instead."
+        if s.device != t.device:
+            return f"Expected {name} to be on {t.device}, but got {s.device} instead."
+    head = (tuple(query.shape[:2]), tuple(key.shape[:2]))
+    token = (tuple(query.shape[:3]), tuple(key.shape[:3]))
+    got = (tuple(scale_q.shape), tuple(scale_k.shape))
+    if got != head and got != token:
+        return (f"Expected scale_q / scale_k of shape {head[0]} / {head[1]} (head-wise) or {token[0]} / {token[1]} "
+                f"(token-wise), but got {got[0]} / {got[1]}.")
+    return None
+
+
 def _validate_hip_input(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None,
-                        scaling_method=None) -> Tuple[bool, str]:
-    """Same contract and messages as _validate_tk_tma_input (nn.py:52-124); differences: token-wise scaling and
-    e5m2 are accepted (the reference routes token-wise to its Triton kernel, nn.py:135-205), GQA is accepted."""
-    if any(t.requires_grad for t in (query, key, value)):
-        return False, "NYI: query, key, and value must be leaf tensors"
-    if attn_mask is not None:
-        return False, "NYI: attn_mask must be None"
-    if dropout_p != 0.0:
-        return False, "NYI: dropout_p must be 0.0"
-    if scale is not None:
-        return False, "NYI: scale must be None"
-    if scaling_method is None:
-        # 16-bit sibling path (nn.py:325-391 -> ops.py:17-45): q, k, v share one 16-bit dtype; D in {64,128}
-        if query.dtype not in (torch.float16, torch.bfloat16):
-            return (
-                False,
-                f"Expected query to have dtype torch.float16 or torch.bfloat16, but got query.dtype: {query.dtype} instead.",
-            )
-        if query.dtype != value.dtype:
-            return (
-                False,
-                f"Expected query and value to have the same dtype, but got query.dtype: {query.dtype}, value.dtype: {value.dtype} instead.",
-            )
-        if query.dim() == 4 and query.size(-1) not in _HIP_16BIT_HEAD_DIMS:
-            return False, f"Unsupported head dimension: {query.size(-1)}"
-    elif scaling_method not in ("head-wise", "token-wise"):
-        return False, f"Unsupported scaling_method: {scaling_method}"
-    if query.dtype not in (torch.float16, torch.bfloat16) + _FP8_DTYPES:
-        return (
-            False,
-            f"Expected query to have dtype torch.float16, torch.bfloat16, or torch.float8_e4m3fn, but got query.dtype: {query.dtype} instead.",
-        )
-    if query.dtype != key.dtype:
-        return (
-            False,
-            f"Expected query and key to have the same dtype, but got query.dtype: {query.dtype}, key.dtype: {key.dtype} instead.",
-        )
-    if value.dtype not in (torch.float16, torch.bfloat16):
-        return (
-            False,
-            f"Expected value to have dtype torch.float16 or torch.bfloat16, but got value.dtype: {value.dtype} instead.",
-        )
-    if query.device != key.device or query.device != value.device:
-        return (
-            False,
-            f"Expected query, key, and value to have the same device type, but got query.device: {query.device}, key.device: {key.device}, and value.device: {value.device} instead.",
-        )
-    if query.device.type != "cuda":
-        return False, "Expected query, key, and value to be on a CUDA device"
-    if query.dim() != 4 or key.dim() != 4 or value.dim() != 4:
-        return False, "NYI: query, key, and value must be 4D tensors"
-    if key.size(-2) != value.size(-2):
-        return (
-            False,
-            f"Expect key and value to have the same sequence length but got Sk={key.size(-2)} and Sv={value.size(-2)}.",
-        )
-    if value.size(-1) != query.size(-1):
-        return False, "NYI: query and value must have the same embedding dimension"
-    if key.size(-3) != value.size(-3) or query.size(-3) % key.size(-3) != 0:
-        return (
-            False,
-            f"Expect the number of query heads to be a multiple of the key/value heads but got Hq={query.size(-3)} and Hkv={key.size(-3)}.",
-        )
-    if not _hip_supported_head_dim(query.size(-1)):
-        return False, f"Unsupported head dimension: {query.size(-1)}"
+                        scaling_method=None, scale_q=None, scale_k=None) -> Tuple[bool, str]:
+    """Contract of _validate_tk_tma_input (nn.py:52-124): first failing rule decides, in the reference's order.
+    Differences: token-wise scaling and e5m2 are accepted (the reference routes token-wise to its Triton kernel,
+    nn.py:135-205), GQA is accepted, and the launcher-level shape checks run here too so that a mismatching key /
+    value / scale raises ValueError before any kernel launch."""
+    call = _Call(query, key, value, attn_mask, dropout_p, scale, scaling_method, scale_q, scale_k)
+    for rule in _RULES:
+        reason = rule(call)
+        if reason:
+            return False, reason
     return True, ""
 
 
@@ -107,27 +201,35 @@ def _pre_check_can_use_hip_attention(device):
 
 
 def can_use_hip_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None,
-                          scaling_method=None) -> Tuple[bool, str]:
+                          scaling_method=None, scale_q=None, scale_k=None) -> Tuple[bool, str]:
     supported, reason = _pre_check_can_use_hip_attention(device=query.device)
     if not supported:
         return False, reason
-    return _validate_hip_input(query, key, value, attn_mask, dropout_p, is_causal, scale, scaling_method=scaling_method)
+    return _validate_hip_input(query, key, value, attn_mask, dropout_p, is_causal, scale, scaling_method=scaling_method,
+                               scale_q=scale_q, scale_k=scale_k)
 
 
 def can_use_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None,
-                      scaling_method=None) -> Tuple[bool, str]:
+                      scaling_method=None, scale_q=None, scale_k=None) -> Tuple[bool, str]:
     if checks.get_constant_attr("quantumattention_amd.config", "attention.skip_supported_check"):
         return True, ""
     supported, reason = can_use_hip_attention(
-        query, key, value, attn_mask, dropout_p, is_causal, scale=scale, scaling_method=scaling_method)
+        query, key, value, attn_mask, dropout_p, is_causal, scale=scale, scaling_method=scaling_method,
+        scale_q=scale_q, scale_k=scale_k)
     if supported:
         return True, ""
     return False, f"[hip_gfx950: {reason}]"
 
 
-def _dynamically_quantize_fp8(t: torch.Tensor, *, reduction_dim=-1, fp8_dtype=torch.float8_e4m3fn):
-    """Eager torch restatement used for CPU / fake tensors and shapes the HIP pre-pass does not cover
-    (the reference's definition, nn.py:14-19)."""
+def _fp8_dtype() -> torch.dtype:
+    return torch.float8_e5m2 if config.attention.fp8_format == "e5m2" else torch.float8_e4m3fn
+
+
+def _dynamically_quantize_fp8(t: torch.Tensor, *, reduction_dim=-1, fp8_dtype=None):
+    """Eager torch restatement used for CPU / fake tensors, shapes the HIP pre-pass does not cover and the
+    force_eager_fallback switch (the reference's definition, nn.py:14-19)."""
+    if fp8_dtype is None:
+        fp8_dtype = _fp8_dtype()
     eps = torch.finfo(torch.float32).eps
     q_max = torch.finfo(fp8_dtype).max
     scale = t.abs().amax(reduction_dim, keepdim=True).mul(1.0 / q_max).clamp_min(eps)
@@ -143,19 +245,42 @@ def _norm_dims(reduction_dim, ndim):
 def dynamically_quantize_fp8(t: torch.Tensor, *, reduction_dim=-1) -> Tuple[torch.Tensor, torch.Tensor]:
     """nn.py:22-42.  4-D CUDA bf16/fp16 tensors reduced over the last dim (token-wise) or the last two
     (head-wise) run the HIP pre-pass (numerics selected by config.attention.quant_numerics, default = the
-    reference's compiled-path numerics); anything else uses the eager torch definition."""
+    reference's compiled-path numerics); anything else uses the eager torch definition (same fp8 format)."""
     from torch._subclasses.fake_tensor import is_fake
 
     dims = _norm_dims(reduction_dim, t.dim())
     hip_ok = (
-        not is_fake(t) and t.is_cuda and t.dim() == 4 and t.dtype in (torch.float16, torch.bfloat16)
+        not is_fake(t) and t.is_cuda and t.dim() == 4 and t.dtype in _HALF_DTYPES
         and dims in ([3], [2, 3]) and t.size(-1) in _HIP_SUPPORTED_HEAD_DIMS and checks.is_gfx950(t.device)
-        and config.attention.enable_hip_kernel
+        and config.attention.enable_hip_kernel and not config.attention.force_eager_fallback
     )
     if not hip_ok:
         return _dynamically_quantize_fp8(t, reduction_dim=reduction_dim)
     return _ops().dynamically_quantize_fp8_op(t, dims == [3], config.attention.fp8_format,
                                               config.attention.quant_numerics)
+
+
+def _expand_kv_heads(x: Tensor, hq: int) -> Tensor:
+    return x if x.size(-3) == hq else x.repeat_interleave(hq // x.size(-3), dim=-3)
+
+
+def _eager_attention(query, key, value, is_causal, scale) -> Tensor:
+    """quantum_attn::attention_forward's eager definition (ops.py:17-29): aten SDPA."""
+    hq = query.size(-3)
+    return torch.nn.functional.scaled_dot_product_attention(
+        query, _expand_kv_heads(key, hq), _expand_kv_heads(value, hq), is_causal=is_causal, scale=scale).contiguous()
+
+
+def _eager_fp8_attention(query, key, value, scale_q, scale_k, is_causal, scale) -> Tensor:
+    """quantum_attn::fp8_attention_forward's eager definition (ops.py:64-95): de-quantise q and k in value's dtype
+    (scales broadcast over the trailing dims they were reduced over), then aten SDPA."""
+    def dequant(x, s):
+        s = s.to(value.dtype)
+        while s.dim() < x.dim():
+            s = s.unsqueeze(-1)
+        return x.to(value.dtype) * s
+
+    return _eager_attention(dequant(query, scale_q), dequant(key, scale_k), value, is_causal, scale)
 
 
 def _attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None) -> Tensor:
@@ -170,6 +295,8 @@ def attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False,
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale)
     if not supported:
         raise ValueError(f"Unsupported input: {reason}")
+    if config.attention.force_eager_fallback:  # nn.py:367-371
+        return _eager_attention(query, key, value, is_causal, scale)
     return _attention_wrapper(query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal,
                               scale=scale)
 
@@ -187,10 +314,19 @@ def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_
             raise ValueError("fp8 query/key need scale_q and scale_k")
         return ops.fp8_quant_attention_forward(
             query, key, value, is_causal, scaling_method, config.attention.fp8_format,
-            config.attention.quant_numerics, scale=scale)
+            config.attention.quant_numerics, config.attention.precision, scale=scale)
     return ops.fp8_attention_forward(
         query, key, value, scale_q, scale_k, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal,
         scale=scale)
+
+
+def _fp8_attention_eager(query, key, value, is_causal, scale, scale_q, scale_k, scaling_method) -> Tensor:
+    """force_eager_fallback: the reference's wrapper run eagerly (nn.py:503-516 -> :394-430 -> ops.py:64-95)."""
+    if scale_q is None:
+        reduction_dim = [query.dim() - 2, query.dim() - 1] if scaling_method == "head-wise" else query.dim() - 1
+        query, scale_q = _dynamically_quantize_fp8(query, reduction_dim=reduction_dim)
+        key, scale_k = _dynamically_quantize_fp8(key, reduction_dim=reduction_dim)
+    return _eager_fp8_attention(query, key, value, scale_q, scale_k, is_causal, scale)
 
 
 def fp8_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None, scale_q=None,
@@ -198,7 +334,7 @@ def fp8_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=Fa
     """nn.py:433-539: validate (ValueError(reason) when unsupported), then run the wrapper."""
     supported, reason = can_use_attention(
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
-        scaling_method=scaling_method)
+        scaling_method=scaling_method, scale_q=scale_q, scale_k=scale_k)
     if not supported:
         raise ValueError(reason)
     if torch.compiler.is_dynamo_compiling():
@@ -206,6 +342,8 @@ def fp8_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=Fa
         for x in [query, key, value]:
             torch._dynamo.mark_static(x, -3)
             torch._dynamo.mark_static(x, -1)
+    elif config.attention.force_eager_fallback:  # nn.py:503-516
+        return _fp8_attention_eager(query, key, value, is_causal, scale, scale_q, scale_k, scaling_method)
     return _fp8_attention_wrapper(
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
         scale_q=scale_q, scale_k=scale_k, scaling_method=scaling_method)

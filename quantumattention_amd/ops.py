@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from . import _native
+from . import _native, config
 
 _custom_op = torch.library.custom_op
 _register_fake = torch.library.register_fake
@@ -45,11 +45,12 @@ def attention_forward(
     _check_op_args(attn_mask, dropout_p, scale)
     if query.dtype not in (torch.bfloat16, torch.float16) or key.dtype != query.dtype or value.dtype != query.dtype:
         raise RuntimeError(f"query/key/value must share bf16 or fp16, got {query.dtype}, {key.dtype}, {value.dtype}")
-    B, Hkv, Skv, D = key.shape
+    _, _, Hkv, _, Skv, _ = _native._check_qkv(query, key, value)
     k_frag = _native.pack16(key, _native.LAYOUT_K16FRAG)
     v_frag = _native.pack16(value, _native.LAYOUT_V16FRAG)
     return _native.attention_forward_16(query, k_frag, v_frag, Hkv=Hkv, Skv=Skv, is_causal=is_causal,
-                                        sm_scale=0.0 if scale is None else float(scale))
+                                        sm_scale=0.0 if scale is None else float(scale),
+                                        fast_exp=bool(config.attention.fast_exp16))
 
 
 @_register_fake("quantumattention_amd::attention_forward")
@@ -77,14 +78,31 @@ def fp8_attention_forward(
         raise RuntimeError("fp8_attention_forward needs scale_q and scale_k")
     if query.dtype not in (torch.float8_e4m3fn, torch.float8_e5m2) or key.dtype != query.dtype:
         raise RuntimeError(f"query/key must share an fp8 dtype, got {query.dtype} and {key.dtype}")
-    scaling = "head-wise" if scale_q.dim() == query.dim() - 2 else "token-wise"
-    B, Hkv, Skv, D = key.shape
+    if value.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError(f"value must be bf16 or fp16, got {value.dtype}")
+    if query.dim() != 4 or key.dim() != 4 or value.dim() != 4:
+        raise RuntimeError("query, key and value must be 4-D")
+    B, Hq, Sq, D = query.shape
+    if key.shape != value.shape or key.shape[0] != B or key.shape[3] != D or key.device != query.device or value.device != query.device:
+        raise RuntimeError(f"key {tuple(key.shape)} / value {tuple(value.shape)} do not match query {tuple(query.shape)} "
+                           "(same batch, head_dim, device; key and value the same shape)")
+    Hkv, Skv = key.shape[1], key.shape[2]
+    if Hkv == 0 or Hq % Hkv != 0:
+        raise RuntimeError(f"Hq={Hq} is not a multiple of Hkv={Hkv}")
+    # scale_q / scale_k: fp32 on the same device, exactly [B,H] (head-wise) or [B,H,S] (token-wise); tk/attention.py:402-414
+    from .nn import scale_shapes_reason
+
+    reason = scale_shapes_reason(query, key, scale_q, scale_k)
+    if reason:
+        raise RuntimeError(reason)
+    scaling = "head-wise" if scale_q.dim() == 2 else "token-wise"
     k_frag = _native.pack_fp8(key, _native.LAYOUT_KFRAG)
     v_frag, scale_v = _native.quant_fp8(value, scaling="head-wise", fp8_dtype=query.dtype,
                                         layout=_native.LAYOUT_VFRAG)
     return _native.fp8_attention_forward(
         query, k_frag, v_frag, scale_q, scale_k, scale_v, Hkv=Hkv, Skv=Skv, out_dtype=value.dtype,
-        is_causal=is_causal, scaling=scaling, sm_scale=0.0 if scale is None else float(scale))
+        is_causal=is_causal, scaling=scaling, sm_scale=0.0 if scale is None else float(scale),
+        precision=config.attention.precision)
 
 
 @_register_fake("quantumattention_amd::fp8_attention_forward")
@@ -101,6 +119,7 @@ def fp8_quant_attention_forward(
     scaling_method: str = "head-wise",
     fp8_format: str = "e4m3",
     numerics: str = "compiled",
+    precision: str = "auto",
     *,
     scale: Optional[float] = None,
 ) -> torch.Tensor:
@@ -109,12 +128,12 @@ def fp8_quant_attention_forward(
     reference through Inductor, without the intermediate row-major K copy."""
     return _native.fp8_quant_attention_forward(
         query, key, value, is_causal=is_causal, scaling=scaling_method, fp8_dtype=_native.FP8_DTYPE[fp8_format],
-        numerics=numerics, sm_scale=0.0 if scale is None else float(scale))
+        numerics=numerics, sm_scale=0.0 if scale is None else float(scale), precision=precision)
 
 
 @_register_fake("quantumattention_amd::fp8_quant_attention_forward")
-def _(query, key, value, is_causal=False, scaling_method="head-wise", fp8_format="e4m3", numerics="compiled", *,
-      scale=None):
+def _(query, key, value, is_causal=False, scaling_method="head-wise", fp8_format="e4m3", numerics="compiled",
+      precision="auto", *, scale=None):
     return _out_like(query, value)
 
 

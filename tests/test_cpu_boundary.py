@@ -28,7 +28,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert getattr(L, n) is not None, n
     lib = _native.lib()
-    assert lib.qattn_abi_version() == _native.ABI_VERSION == 3
+    assert lib.qattn_abi_version() == _native.ABI_VERSION == 4
 
 
 def test_abi_size_queries_and_error_codes_need_no_gpu():
@@ -39,17 +39,26 @@ def test_abi_size_queries_and_error_codes_need_no_gpu():
     assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_HEAD) == 4 * 32 * 4
     assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_TOKEN) == 0
     assert L.qattn_quant_qkv_workspace_bytes(4, 32, 8) == 4 * (32 + 16) * 4
+    assert L.qattn_attention_workspace_bytes(4, 32, 4096) == 4 * 32 * 16 * 4           # one word per 256-row query block
+    assert L.qattn_fp8_quant_attention_workspace_bytes(4, 32, 8, 4096) == 4 * (32 + 16) * 4 + 4 * 32 * 16 * 4   # both parts multiples of 16
+    assert L.qattn_lse_row_stride(1000, _native.LSE_NATURAL) == 1000
+    assert L.qattn_lse_row_stride(1001, _native.LSE_REFERENCE) == 1004                 # row padded to 16 bytes (tk/attention.py:439)
     for code in range(0, -7, -1):
         assert L.qattn_strerror(code)
     assert b"unknown" in L.qattn_strerror(-99)
     # validation happens before any HIP call: NULL pointers / bad dims are rejected on a CPU-only box too
-    assert L.qattn_fp8_attention_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 128, 0, 0, 2, 0, 0, 0.0, None) == -1
+    attn = lambda *a: L.qattn_fp8_attention_forward(*a)
+    assert attn(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 128, 0, 0, 2, 0, 0, 0.0, 1, 0, None, 0, None) == -1
     assert L.qattn_quant_fp8(None, 2, None, None, 1, 1, 1, 128, 0, 0, 0, 0, None, 0, None) == -1
     assert L.qattn_pack_fp8(None, None, 1, 1, 1, 128, 1, None) == -1
     one = ctypes.c_void_p(16)  # any non-NULL pointer: dimension checks come first
-    assert L.qattn_fp8_attention_forward(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 96, 0, 0, 2, 0, 0, 0.0, None) == -2
-    assert L.qattn_fp8_attention_forward(one, one, one, one, None, one, one, None, 1, 3, 2, 8, 8, 128, 0, 0, 2, 0, 0, 0.0, None) == -2
-    assert L.qattn_fp8_attention_forward(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 128, 2, 2, 2, 0, 0, 0.0, None) == -3
+    assert attn(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 96, 0, 0, 2, 0, 0, 0.0, 1, 0, None, 0, None) == -2
+    assert attn(one, one, one, one, None, one, one, None, 1, 3, 2, 8, 8, 128, 0, 0, 2, 0, 0, 0.0, 1, 0, None, 0, None) == -2
+    assert attn(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 128, 2, 2, 2, 0, 0, 0.0, 1, 0, None, 0, None) == -3
+    assert attn(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 128, 0, 0, 2, 0, 0, 0.0, 7, 0, None, 0, None) == -1   # precision enum
+    assert attn(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 128, 0, 0, 2, 0, 0, 0.0, 1, 5, None, 0, None) == -1   # lse_layout enum
+    # QATTN_PRECISION_AUTO needs its flag workspace: rejected before anything is launched
+    assert attn(one, one, one, one, None, one, one, None, 1, 1, 1, 8, 8, 128, 0, 0, 2, 0, 0, 0.0, 0, 0, None, 0, None) == -4
 
 
 def test_public_names_and_signatures_mirror_the_reference():
@@ -62,7 +71,7 @@ def test_public_names_and_signatures_mirror_the_reference():
     assert list(inspect.signature(qa.attn_func).parameters) == sdpa                                   # interface.py:41-50
     assert list(inspect.signature(qa.fp8_attn_func).parameters) == sdpa + ["scale_q", "scale_k", "scaling_method"]  # :101-113
     assert list(inspect.signature(qa.fp8_token_wise_attn_func).parameters) == sdpa + ["scale_q", "scale_k"]         # :179-190
-    assert list(inspect.signature(qa.nn.can_use_attention).parameters) == sdpa + ["scaling_method"]  # nn.py:282-292
+    assert list(inspect.signature(qa.nn.can_use_attention).parameters)[:8] == sdpa + ["scaling_method"]  # nn.py:282-292
     for flag in ("skip_supported_check", "force_eager_fallback"):                                   # config.py:27-28
         assert hasattr(qa.config.attention, flag)
     with qa.config.patch({"attention.skip_supported_check": True}):                                 # config.py:34-41
@@ -127,3 +136,66 @@ def test_fake_impls_of_every_custom_op_without_a_gpu():
         assert o.shape == q.shape and o.dtype == torch.float16   # output takes value's dtype (tk/attention.py:434-437)
         o = torch.ops.quantumattention_amd.attention_forward(q, q, q, None, 0.0, True)
         assert o.shape == q.shape and o.dtype == torch.bfloat16
+
+
+def _fake_cuda(*shape, dtype=torch.bfloat16):
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    with FakeTensorMode():
+        return torch.empty(*shape, dtype=dtype, device="cuda")
+
+
+def test_validation_rules_reject_mismatching_key_value_and_scales_before_any_launch():
+    """batch / head_dim agreement and the scale tensors are checked in Python (reasons, not GPU faults) -- the
+    checks the reference's launcher does with TORCH_CHECK (tk/attention.py:385-414).  Fake cuda tensors: no GPU needed."""
+    v = qa.nn._validate_hip_input
+    q = _fake_cuda(2, 4, 64, 128)
+    assert v(q, q, q, scaling_method="head-wise") == (True, "")
+    ok, why = v(q, _fake_cuda(1, 4, 64, 128), _fake_cuda(1, 4, 64, 128), scaling_method="head-wise")
+    assert not ok and "batch size" in why
+    ok, why = v(q, _fake_cuda(2, 4, 64, 64), q, scaling_method="head-wise")
+    assert not ok and "embedding dimension" in why and "Dk=64" in why
+    ok, why = v(q, _fake_cuda(2, 3, 64, 128), _fake_cuda(2, 3, 64, 128), scaling_method="head-wise")
+    assert not ok and "multiple of the key/value heads" in why
+    q8 = _fake_cuda(2, 4, 64, 128, dtype=torch.float8_e4m3fn)
+    s = _fake_cuda(2, 4, dtype=torch.float32)
+    assert v(q8, q8, q, scaling_method="head-wise", scale_q=s, scale_k=s) == (True, "")
+    assert v(q8, q8, q, scaling_method="token-wise", scale_q=_fake_cuda(2, 4, 64, dtype=torch.float32), scale_k=_fake_cuda(2, 4, 64, dtype=torch.float32))[0]
+    assert "both provided" in v(q8, q8, q, scaling_method="head-wise", scale_q=s)[1]
+    assert "need scale_q" in v(q8, q8, q, scaling_method="head-wise")[1]
+    assert "float32" in v(q8, q8, q, scaling_method="head-wise", scale_q=s.bfloat16(), scale_k=s)[1]
+    assert "shape" in v(q8, q8, q, scaling_method="head-wise", scale_q=_fake_cuda(2, 3, dtype=torch.float32), scale_k=s)[1]
+    assert "shape" in v(q8, q8, q, scaling_method="head-wise", scale_q=s, scale_k=_fake_cuda(2, 4, 64, dtype=torch.float32))[1]
+    assert "only accepted with fp8" in v(q, q, q, scaling_method="head-wise", scale_q=s, scale_k=s)[1]
+    # the reference's reasons, in the reference's order (nn.py:63-121)
+    assert v(q, q, q, dropout_p=0.1, scaling_method="head-wise")[1] == "NYI: dropout_p must be 0.0"
+    assert v(q, q, q, scale=0.5, scaling_method="head-wise")[1] == "NYI: scale must be None"
+    assert v(q, q, q, scaling_method="row-wise")[1] == "Unsupported scaling_method: row-wise"
+    assert v(_fake_cuda(2, 4, 64, 96), _fake_cuda(2, 4, 64, 96), _fake_cuda(2, 4, 64, 96), scaling_method="head-wise")[1] == "Unsupported head dimension: 96"
+
+
+def test_force_eager_fallback_runs_the_ops_eager_definition():
+    """config.attention.force_eager_fallback keeps the reference's meaning (nn.py:367-371, 503-516): the wrapper runs
+    eagerly -- eager quantiser + de-quantise + aten SDPA (ops.py:64-95).  On CPU tensors with the support check skipped
+    the result must equal the reference's own eager output stored in the golden file, bit for bit."""
+    z = np.load(os.path.join(GOLDEN, "c1_b1h2s128d64_bf16_s0.npz"))
+    to_t = lambda b: torch.from_numpy(b.view(np.int16).copy()).view(torch.bfloat16)
+    q, k, v = to_t(z["q"]), to_t(z["k"]), to_t(z["v"])
+    torch.set_num_threads(4)
+    with qa.config.patch({"attention.force_eager_fallback": True, "attention.skip_supported_check": True}):
+        for causal in (False, True):
+            q8 = torch.from_numpy(z["q8_head_compiled"].copy()).view(torch.float8_e4m3fn)
+            k8 = torch.from_numpy(z["k8_head_compiled"].copy()).view(torch.float8_e4m3fn)
+            out = qa.fp8_attn_func(q8, k8, v, is_causal=causal, scale_q=torch.from_numpy(z["sq_head_compiled"]),
+                                   scale_k=torch.from_numpy(z["sk_head_compiled"]))
+            ref = to_t(z[f"o1_head_{'causal' if causal else 'full'}"])
+            assert (out.float() - ref.float()).abs().max() <= 2.0 ** -8   # same aten kernel; thread partition may differ
+            out16 = qa.attn_func(q, k, v, is_causal=causal)
+            ref16 = to_t(z[f"o16_{'causal' if causal else 'full'}"])
+            assert (out16.float() - ref16.float()).abs().max() <= 2.0 ** -8
+        # 16-bit inputs: quantised by the eager definition first (nn.py:410-418), e4m3 unless the format flag says otherwise
+        out = qa.fp8_attn_func(q, k, v)
+        assert out.dtype == torch.bfloat16 and out.shape == q.shape and torch.isfinite(out).all()
+        with qa.config.patch({"attention.fp8_format": "e5m2"}):
+            q8, _ = qa.dynamically_quantize_fp8(q, reduction_dim=[2, 3])
+            assert q8.dtype == torch.float8_e5m2   # ADVICE r1: the eager fallback follows config.attention.fp8_format

@@ -146,7 +146,7 @@ def test_unsupported_inputs_raise_or_fall_back_like_the_reference():
         qa.fp8_attn_func(q, q, q, scale=0.5)
     with pytest.raises(ValueError, match="attn_mask"):
         qa.fp8_attn_func(q, q, q, attn_mask=torch.ones(128, 128, dtype=torch.bool, device="cuda"))
-    assert _native.lib().qattn_fp8_attention_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 128, 0, 0, 2, 0, 0, 0.0, None) == -1
+    assert _native.lib().qattn_fp8_attention_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 128, 0, 0, 2, 0, 0, 0.0, 1, 0, None, 0, None) == -1
     assert _native.lib().qattn_check_device() == 0
 
 
@@ -285,11 +285,16 @@ def test_c_abi_error_codes_instead_of_exceptions():
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     f0 = ctypes.c_float(0.0)
 
-    def attn(D=128, Hq=2, Hkv=2, qk=0, vf=0, of=2, mode=0, q=q8):
-        return L.qattn_fp8_attention_forward(P(q) if q is not None else None, P(q8), P(q8), P(out), None, P(sc), P(sc), None,
-                                             1, Hq, Hkv, 64, 64, D, qk, vf, of, mode, 0, f0, None)
+    wsb = torch.zeros(64, dtype=torch.uint8, device="cuda")
 
-    assert attn() == 0
+    def attn(D=128, Hq=2, Hkv=2, qk=0, vf=0, of=2, mode=0, q=q8, precision=0, lse_layout=0, ws=wsb, ws_bytes=64):
+        return L.qattn_fp8_attention_forward(P(q) if q is not None else None, P(q8), P(q8), P(out), None, P(sc), P(sc), None,
+                                             1, Hq, Hkv, 64, 64, D, qk, vf, of, mode, 0, f0, precision, lse_layout,
+                                             P(ws) if ws is not None else None, ctypes.c_size_t(ws_bytes), None)
+
+    assert attn() == 0 and attn(precision=1, ws=None, ws_bytes=0) == 0 and attn(precision=2, ws=None, ws_bytes=0) == 0
+    assert attn(ws=None, ws_bytes=0) == -4 and attn(ws_bytes=4) == -4       # QATTN_PRECISION_AUTO needs its flag words
+    assert attn(precision=3) == -1 and attn(lse_layout=2) == -1
     assert attn(D=96) == -2 and L.qattn_strerror(-2) is not None       # head_dim not in {64,128,256} (nn.py:45-49)
     assert attn(Hq=3, Hkv=2) == -2                                     # Hq % Hkv != 0
     assert attn(qk=2) == -3 and attn(vf=1) == -3 and attn(of=0) == -3  # formats
@@ -303,7 +308,7 @@ def test_c_abi_error_codes_instead_of_exceptions():
     assert quant(ws_bytes=4) == -4                                      # workspace too small (needs 2 heads x 4 bytes)
     assert quant(D=100) == -2 and quant(in_fmt=0) == -3 and quant(out_fmt=2) == -3
     assert L.qattn_pack16(P(x), P(x8), 1, 2, 64, 96, 3, None) == -2     # head_dim not in {64,128,256}
-    assert L.qattn_attention_forward_16(P(x), P(x), P(x), P(out), None, 1, 2, 2, 64, 64, 128, 0, 0, f0, None) == -3
+    assert L.qattn_attention_forward_16(P(x), P(x), P(x), P(out), None, 1, 2, 2, 64, 64, 128, 0, 0, f0, 0, None) == -3
     torch.cuda.synchronize()
     for code in (0, -1, -2, -3, -4, -5, -6):
         assert len(L.qattn_strerror(code)) > 0

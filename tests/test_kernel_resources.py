@@ -1,0 +1,37 @@
+"""No shipped kernel may spill registers or use scratch memory: compile the product sources for gfx950 with -save-temps
+(hipcc cross-compiles without a GPU) and read .vgpr_spill_count / .private_segment_fixed_size of every kernel from the
+code-object metadata.  Uses the build directory `__graft_entry__.build()` / build.py fill."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources  # noqa: E402
+
+
+def test_every_shipped_kernel_is_free_of_spills_and_scratch():
+    from quantumattention_amd import build as hip_build
+
+    hip_build.build(save_temps=True)   # no-op when the objects and their .s files are current
+    d = hip_build.BUILD
+    files = [f for f in os.listdir(d) if f.endswith("gfx950.s")]
+    missing = [s for s in hip_build.SOURCES if not any(f.startswith(s.replace(".hip", "")) for f in files)]
+    if missing:   # objects were built without -save-temps: rebuild those files once with it
+        hip_build.build(force=True, save_temps=True)
+        files = [f for f in os.listdir(d) if f.endswith("gfx950.s")]
+    total, bad = 0, []
+    for f in sorted(files):
+        if not any(f.startswith(s.replace(".hip", "")) for s in hip_build.SOURCES):
+            continue   # stale file of a source that is no longer part of the product
+        for r in kernel_resources.parse(os.path.join(d, f)):
+            total += 1
+            # (SGPR spills go to VGPR lanes, not memory: a few in the prologues of the 106-SGPR attention kernels are tolerated)
+            if r.get("vgpr_spill_count", 0) or r.get("private_segment_fixed_size", 0) or r.get("sgpr_spill_count", 0) > 16:
+                bad.append((r["name"], r.get("vgpr_count"), r.get("vgpr_spill_count"), r.get("private_segment_fixed_size")))
+            assert r["vgpr_count"] <= 256, r   # two waves per SIMD for the 512-thread attention kernels
+    assert total >= 100, total   # quant + pack + attention (fp8, 16-bit) instantiations
+    assert not bad, bad
