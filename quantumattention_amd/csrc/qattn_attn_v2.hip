@@ -525,6 +525,150 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     for (; t < T; ++t) sync_iter(t);
 }
 
+// Row-group rescue (QATTN_PRECISION_AUTO): recompute the 32 query rows of ONE wave of this
+// workgroup with exact exponentials and two-term P, the key range split over all NW waves (each takes a contiguous run of
+// 64-key chunks, reads the K / V fragments straight from global memory / L2 -- the ring is idle -- and keeps a partial
+// {O, m, l}); the partials are merged pairwise through LDS (three rounds) and wave 0 stores the rows.  Used when at most
+// kMaxRescueWaves waves of a block hold a peaked row: ~0.3 of a block's sweep instead of the 1.5 of repeating the block.
+constexpr int kMaxRescueWaves = 2;
+
+__device__ __forceinline__ v8i gload_frag(const unsigned char* base) {
+    const v4i lo = *reinterpret_cast<const v4i*>(base);
+    const v4i hi = *reinterpret_cast<const v4i*>(base + 512);
+    v8i r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL>
+__device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
+                                            int q0_wg, int fw, int wave, int lane, long bh, long kv_head, float c) {
+    static_assert(NW == 8, "three merge rounds");
+    constexpr int CH = 64 * D, STAGE = 2 * CH, KS = D / 64, MB = D / 32;
+    constexpr int SLOT = (MB * 16 + 2) * 64 * 4;   // one wave's partial {O^T, m, l} in LDS
+    static_assert(4 * SLOT <= kStagesV2 * STAGE, "four partials fit the K/V ring");
+    const int ql = lane & 31, hh = lane >> 5;
+    const int r0 = q0_wg + fw * kQPerWave, row = r0 + ql;
+    const int frag_lane_off = (hh << 10) + (ql << 4);
+    // the rescued wave's Q^T fragments are still parked in its LDS slots
+    const unsigned char* qsrc = smem + kStagesV2 * STAGE + fw * (KS << 11) + frag_lane_off;
+    v8i qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) qf[s] = lds_read_frag(qsrc + (s << 11));
+    const int n_r = CAUSAL ? min(p.nchunks, (min(r0 + kQPerWave, p.Sq) - 1) / 64 + 1) : p.nchunks;
+    const int per = (n_r + NW - 1) / NW;
+    const int t0 = wave * per, t1 = min(n_r, t0 + per);
+    v16f o[MB];
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
+    float m_run = -1.0e30f, l_run = 0.0f;
+    for (int t = t0; t < t1; t++) {
+        const unsigned char* kc = kg + (long)t * CH + frag_lane_off;
+        const unsigned char* vc = vg + (long)t * CH + frag_lane_off;
+        v16f s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const v8i ka = gload_frag(kc + ((0 * KS + s) << 11)), kb = gload_frag(kc + ((1 * KS + s) << 11));
+            s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf[s], s0);
+            s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf[s], s1);
+        }
+        v8i vf[MB];
+#pragma unroll
+        for (int m = 0; m < MB; m++) vf[m] = gload_frag(vc + (m << 11));   // in flight under the softmax
+        prep_scores<CAUSAL, false>(s0, s1, p, t * 64, r0, row, hh, nullptr);
+        float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
+        mx = fmaxf(mx, s0[15]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (__any((mx - m_run) * c > kRescaleThr)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[m][r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+        const float mc = kPShift - m_run * c;
+        v8i ph, pl;
+        float ls = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const v16f& sx = w < 4 ? s0 : s1;
+            const int j = w & 3;
+            float e[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[4 * j + i], c, mc)); ls += e[i]; }
+            int hi = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], 0);
+            hi = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2], e[3], hi);
+            const float h0 = __builtin_amdgcn_cvt_f32_fp8(hi, 0), h1 = __builtin_amdgcn_cvt_f32_fp8(hi, 1);
+            const float h2 = __builtin_amdgcn_cvt_f32_fp8(hi, 2), h3 = __builtin_amdgcn_cvt_f32_fp8(hi, 3);
+            int lo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h0, e[1] - h1, 0);
+            lo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h2, e[3] - h3, lo);
+            ph[w] = hi; pl[w] = lo;
+        }
+        l_run += ls;
+#pragma unroll
+        for (int m = 0; m < MB; m++) {
+            o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], ph, o[m]);
+            o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], pl, o[m]);
+        }
+    }
+    // ---- merge the NW partials pairwise through LDS: {4..7} -> {0..3}, {2,3} -> {0,1}, {1} -> {0}
+    float* slots = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            float* d = slots + (wave - half) * (SLOT / 4);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++)
+                    *reinterpret_cast<v4f*>(d + ((m * 4 + r4) * 64 + lane) * 4) = v4f{o[m][4 * r4], o[m][4 * r4 + 1], o[m][4 * r4 + 2], o[m][4 * r4 + 3]};
+            d[MB * 16 * 64 + lane] = m_run;
+            d[(MB * 16 + 1) * 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float* d = slots + wave * (SLOT / 4);
+            const float m_b = d[MB * 16 * 64 + lane], l_b = d[(MB * 16 + 1) * 64 + lane];
+            const float m_new = fmaxf(m_run, m_b);
+            const float fa = __builtin_amdgcn_exp2f((m_run - m_new) * c), fb = __builtin_amdgcn_exp2f((m_b - m_new) * c);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const v4f ob = *reinterpret_cast<const v4f*>(d + ((m * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[m][4 * r4 + i] = o[m][4 * r4 + i] * fa + ob[i] * fb;
+                }
+            l_run = l_run * fa + l_b * fb;
+            m_run = m_new;
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const float sv = p.sv ? p.sv[kv_head] : 1.0f;
+        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + row, hh, row < p.Sq);
+        if (p.lse && hh == 0 && row < p.Sq)
+            p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
+    }
+}
+
 // One pass of a wave over its KV range with P in TWO (hi + lo) or one term, BYTE-exponential or exact, followed by the
 // row sums.  Returns true when `check_peaked` is set and some row of the WORKGROUP turned out to be peaked (its largest
 // softmax weight 1 / R exceeds 1 / peak_r0): nothing has been stored then and the caller repeats the block in two-term
@@ -597,9 +741,33 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
             d[0] = l_tot; d[1] = st.m_true; d[2] = m_run; d[3] = c;
         }
 #endif
-        if (__any(peaked) && lane == 0) *vote = 1u;
-        __syncthreads();
-        if (*vote != 0u) return true;
+        // per-wave votes -> the set of waves of this workgroup that hold a peaked row (workgroup-uniform after the barrier)
+#ifdef QATTN_DEV
+        const bool mine = p.peak_r0 > 1.0e6f ? wave == 0 : __any(peaked) != 0;   // QATTN_PEAK_R0=1e7: rescue wave 0 of every block (timing)
+#else
+        const bool mine = __any(peaked) != 0;
+#endif
+        if (lane == 0) vote[wave] = mine ? 1u : 0u;
+        __syncthreads();   // also: every wave is done with the K/V ring
+        unsigned flagged = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) flagged |= (vote[w] != 0u ? 1u : 0u) << w;
+        flagged = __builtin_amdgcn_readfirstlane(flagged);
+        const int nf = __builtin_popcount(flagged);
+        if (nf > kMaxRescueWaves) return true;   // many peaked rows: the whole block repeats in two-term mode
+        const float sv = p.sv ? p.sv[kv_head] : 1.0f;
+        if (!mine) {
+            store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq);
+            if (p.lse && hh == 0 && qrow < p.Sq)
+                p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
+        }
+        if constexpr (!TOKEN && NW == 8) {
+            for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u)
+                rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL>(p, smem, kg, vg, q0 - wave * kQPerWave, __builtin_ctz(rest), wave, lane, bh, kv_head, c);
+        } else {
+            if (nf > 0) return true;
+        }
+        return false;
     }
 
     // ---- normalise, convert, store
@@ -648,7 +816,7 @@ __device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* s
 
     // Q^T fragments: global -> this lane's own slots of the workgroup's Q area in LDS (behind the K/V ring);
     // only the writing lane ever reads them back, so no barrier is needed (the compiler orders the lane's own
-    // ds_write -> ds_read with lgkmcnt).  One word behind the Q area collects the workgroup's "a row is peaked" vote.
+    // ds_write -> ds_read with lgkmcnt).  NW words behind the Q area collect the waves' "a row of mine is peaked" votes.
     unsigned char* qbuf = smem + kStagesV2 * STAGE + wave * (KS << 11) + (hh << 10) + (ql << 4);
     unsigned* vote = reinterpret_cast<unsigned*>(smem + kStagesV2 * STAGE + NW * kQPerWave * D);
     float scale_q16 = 1.0f;
@@ -714,8 +882,6 @@ __device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* s
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int VOTE_OFF = kStagesV2 * 2 * 64 * D + NW * kQPerWave * D;
-    if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(smem + VOTE_OFF) = 0u;  // ordered before any vote by the barriers of the sweep
     int head, qb;
     map_block(p, blockIdx.x, p.nqb, CAUSAL, head, qb);
     // One copy of each pass: a peaked block loops back into the two-term code that the blocks qb < n_two enter directly.
@@ -737,7 +903,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
 template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16 = false>
 static int launch_attn_v2_one(const AttnParams& p, hipStream_t st) {
     const int grid = p.B * p.Hq * p.nqb;
-    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 16;  // K/V ring + parked Q^T fragments + vote word
+    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64;  // K/V ring + parked Q^T fragments + per-wave vote words
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
 #endif
@@ -759,7 +925,7 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
         const int grid = p.B * p.Hq * p.nqb;
-        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 16;
+        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64;
         p.n_two = 0; p.peak_r0 = 0.0f;
 #define QATTN_ABL_CASE(M)                                                                                          \
         case M: {                                                                                                  \

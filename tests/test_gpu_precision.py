@@ -85,14 +85,14 @@ def test_groups_of_equally_heavy_keys():
 
 def test_flat_rows_keep_the_one_term_result_bit_for_bit():
     """The check must not change what flat inputs compute: on N(0,1) data at S = 4096 `auto` and `fast` agree bit for bit
-    except in blocks that were redone, and those are rare (< 5 % of the rows)."""
+    except in the 32-row groups that were rescued, and those are rare (< 5 % of the rows)."""
     torch.manual_seed(0)
     q, k, v = (torch.randn(2, 8, 4096, 128, dtype=torch.bfloat16) for _ in range(3))
     a, f = _run(q, k, v, False, "auto"), _run(q, k, v, False, "fast")
     changed = (a != f).any(axis=-1)            # rows that differ
     assert changed.mean() < 0.05, changed.mean()
-    blocks = changed.reshape(2, 8, 16, 256)
-    assert ((blocks.any(-1)) == (blocks.mean(-1) > 0.5)).all()   # a redone block changes (almost) all of its rows, others none
+    groups = changed.reshape(2, 8, 128, 32)
+    assert ((groups.any(-1)) == (groups.mean(-1) > 0.5)).all()   # a rescued 32-row group changes (almost) all of its rows, others none
     ref = _oracle(q[:1, :2], k[:1, :2], v[:1, :2], False)
     assert err_stats(a[:1, :2], ref)[0] < TOL
     assert err_stats(f[:1, :2], ref)[0] < TOL      # the unchecked one-term path is accurate on flat rows
