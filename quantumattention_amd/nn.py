@@ -20,6 +20,12 @@ _FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
 _HALF_DTYPES = (torch.float16, torch.bfloat16)
 
 
+def _cfg(name: str):
+    """config.attention.<name>, readable under torch.compile(fullgraph=True): dynamo does not trace the config proxy's
+    __getattr__, so the lookup goes through an assume_constant_result helper as in the reference (utils/checks.py)."""
+    return checks.get_constant_attr("quantumattention_amd.config", f"attention.{name}")
+
+
 def _ops():
     from . import ops  # registers the custom ops (imports the native binding lazily at call time)
 
@@ -193,7 +199,7 @@ def _validate_hip_input(query, key, value, attn_mask=None, dropout_p=0.0, is_cau
 def _pre_check_can_use_hip_attention(device):
     if device.type != "cuda":
         return False, f"Expected device to be on a CUDA device, but got device: {device} instead."
-    if not config.attention.enable_hip_kernel:
+    if not _cfg("enable_hip_kernel"):
         return False, "gfx950 HIP kernel is disabled"
     if not checks.is_gfx950(device):
         return False, "An AMD gfx950 (MI355X) device under PyTorch-ROCm is required"
@@ -222,7 +228,7 @@ def can_use_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causa
 
 
 def _fp8_dtype() -> torch.dtype:
-    return torch.float8_e5m2 if config.attention.fp8_format == "e5m2" else torch.float8_e4m3fn
+    return torch.float8_e5m2 if _cfg("fp8_format") == "e5m2" else torch.float8_e4m3fn
 
 
 def _dynamically_quantize_fp8(t: torch.Tensor, *, reduction_dim=-1, fp8_dtype=None):
@@ -252,12 +258,12 @@ def dynamically_quantize_fp8(t: torch.Tensor, *, reduction_dim=-1) -> Tuple[torc
     hip_ok = (
         not is_fake(t) and t.is_cuda and t.dim() == 4 and t.dtype in _HALF_DTYPES
         and dims in ([3], [2, 3]) and t.size(-1) in _HIP_SUPPORTED_HEAD_DIMS and checks.is_gfx950(t.device)
-        and config.attention.enable_hip_kernel and not config.attention.force_eager_fallback
+        and _cfg("enable_hip_kernel") and not _cfg("force_eager_fallback")
     )
     if not hip_ok:
         return _dynamically_quantize_fp8(t, reduction_dim=reduction_dim)
-    return _ops().dynamically_quantize_fp8_op(t, dims == [3], config.attention.fp8_format,
-                                              config.attention.quant_numerics)
+    return _ops().dynamically_quantize_fp8_op(t, dims == [3], _cfg("fp8_format"),
+                                              _cfg("quant_numerics"))
 
 
 def _expand_kv_heads(x: Tensor, hq: int) -> Tensor:
@@ -295,7 +301,7 @@ def attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False,
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale)
     if not supported:
         raise ValueError(f"Unsupported input: {reason}")
-    if config.attention.force_eager_fallback:  # nn.py:367-371
+    if _cfg("force_eager_fallback"):  # nn.py:367-371
         return _eager_attention(query, key, value, is_causal, scale)
     return _attention_wrapper(query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal,
                               scale=scale)
@@ -313,8 +319,8 @@ def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_
         if query.dtype in _FP8_DTYPES:
             raise ValueError("fp8 query/key need scale_q and scale_k")
         return ops.fp8_quant_attention_forward(
-            query, key, value, is_causal, scaling_method, config.attention.fp8_format,
-            config.attention.quant_numerics, config.attention.precision, scale=scale)
+            query, key, value, is_causal, scaling_method, _cfg("fp8_format"),
+            _cfg("quant_numerics"), _cfg("precision"), scale=scale)
     return ops.fp8_attention_forward(
         query, key, value, scale_q, scale_k, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal,
         scale=scale)
@@ -342,7 +348,7 @@ def fp8_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=Fa
         for x in [query, key, value]:
             torch._dynamo.mark_static(x, -3)
             torch._dynamo.mark_static(x, -1)
-    elif config.attention.force_eager_fallback:  # nn.py:503-516
+    elif _cfg("force_eager_fallback"):  # nn.py:503-516
         return _fp8_attention_eager(query, key, value, is_causal, scale, scale_q, scale_k, scaling_method)
     return _fp8_attention_wrapper(
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale,

@@ -12,7 +12,14 @@ stored here comes from the reference's own functions:
   * quantum_attn.ops._attention_forward                (16-bit sibling op, ops.py:17-29)
   * quantum_attn.*_with_fallback on CPU tensors        (interface.py:62-98,134-176,209-248)
 
-Outputs are data only (npz with raw bit patterns); no reference source is copied.
+Besides the reference's own outputs the files hold two fp64-evaluated oracles on the SAME quantised inputs (SURVEY.md
+section 8c), computed with torch.float64 ops on the reference's q8 / k8 / scales:
+  o2_*  = softmax((sq q8)(sk k8)^T / sqrt(D) [+ causal mask]) v            (v = the 16-bit tensor, exact in fp64)
+  o3_*  = the same with v replaced by sv * v8, (v8, sv) = quantum_attn.dynamically_quantize_fp8(v, [2,3])
+and, for the e5m2 format the reference does not have, the torch restatement of its compiled quantiser numerics with
+torch.float8_e5m2 (`*_e5m2` keys: scale = amax * (1/57344) in fp32, payload = e5m2(clamp(round_to_input_dtype(fp32(t) / scale)))).
+
+Outputs are data only (npz with raw bit patterns / fp32 arrays); no reference source is copied.
 Usage:  python tests/golden/gen_golden.py
 """
 import os
@@ -40,6 +47,24 @@ def bits16(t):
 
 def bits8(t):
     return t.contiguous().view(torch.uint8).numpy().copy()
+
+
+def sdpa64(q8, k8, v64, sq, sk, causal, token):
+    """fp64 SDPA on de-quantised q8, k8 (scales applied in fp64): the definition ops.py:64-95 evaluates in 16 bit."""
+    q = q8.to(torch.float64) * (sq.double()[..., None] if token else sq.double()[..., None, None])
+    k = k8.to(torch.float64) * (sk.double()[..., None] if token else sk.double()[..., None, None])
+    s = q @ k.transpose(-1, -2) / (q.shape[-1] ** 0.5)
+    if causal:
+        s = s.masked_fill(~torch.ones(s.shape[-2:], dtype=torch.bool).tril(), float("-inf"))
+    return (torch.softmax(s, -1) @ v64).to(torch.float32).numpy()
+
+
+def quant_e5m2_compiled(t, rdim):
+    """torch restatement of the compiled quantiser numerics (nn.py:14-19 as Inductor evaluates it) for float8_e5m2."""
+    qmax = 57344.0
+    scale = t.float().abs().amax(rdim, keepdim=True).mul(1.0 / qmax).clamp_min(torch.finfo(torch.float32).eps)
+    payload = (t.float() / scale).to(t.dtype).clamp(-qmax, qmax).to(torch.float8_e5m2)
+    return payload, scale.squeeze(rdim)
 
 
 def main():
@@ -81,11 +106,28 @@ def main():
                 out[f"k8_{method}_eager"] = bits8(k8e)
                 out[f"sq_{method}_eager"] = sqe.numpy().copy()
                 out[f"sk_{method}_eager"] = ske.numpy().copy()
+            if method == "head":
+                v8, sv = qa.dynamically_quantize_fp8(v, reduction_dim=[2, 3])   # the build also quantises V, head-wise
+                out["v8_head_compiled"] = bits8(v8)
+                out["sv_head_compiled"] = sv.numpy().copy()
+                v3 = v8.to(torch.float64) * sv.double()[..., None, None]
+            q5, sq5 = quant_e5m2_compiled(q, rdim)
+            k5, sk5 = quant_e5m2_compiled(k, rdim)
+            out[f"q8_{method}_e5m2"], out[f"sq_{method}_e5m2"] = bits8(q5), sq5.numpy().copy()
+            out[f"k8_{method}_e5m2"], out[f"sk_{method}_e5m2"] = bits8(k5), sk5.numpy().copy()
             for causal in (False, True):
                 if causal and Sq != Skv:
                     continue  # reference tests skip this (tests/test_interface.py:32-33)
+                tag = "causal" if causal else "full"
                 o1 = qops._fp8_attention_forward(q8, k8, v, sq, sk, is_causal=causal)
-                out[f"o1_{method}_{'causal' if causal else 'full'}"] = bits16(o1)
+                out[f"o1_{method}_{tag}"] = bits16(o1)
+                # fp64 oracles, kept small: every ROW_STEP-th query row (all of them for the short shapes), token-wise only there
+                step = 1 if Sq <= 128 else 4
+                if method == "head" or step == 1:
+                    out[f"o2_{method}_{tag}"] = sdpa64(q8, k8, v.double(), sq, sk, causal, method == "token")[:, :, ::step].copy()
+                if method == "head":
+                    out[f"o3_{method}_{tag}"] = sdpa64(q8, k8, v3, sq, sk, causal, False)[:, :, ::step].copy()
+                out["o23_row_step"] = np.array([step], dtype=np.int64)
         for causal in (False, True):
             if causal and Sq != Skv:
                 continue

@@ -47,6 +47,11 @@ def test_op_on_reference_quantised_inputs_vs_oracle_and_golden(name, method):
                                   z[f"sk_{method}_compiled"], v_dtype=dtype, scaling=method, causal=causal)
         mx, rmse = err_stats(got, ref)
         assert mx < tol_for(ref), (key, mx, rmse)
+        if method == "head":   # the committed fp64 fixture O3 (reference q8 / k8 / v8 / scales), no oracle code in the loop
+            step = int(z["o23_row_step"][0])
+            o3 = z[f"o3_head_{'causal' if causal else 'full'}"]
+            mx3, _ = err_stats(got[:, :, ::step], o3)
+            assert mx3 < tol_for(o3), (key, mx3)
         # distance to the reference's literal eager output O1 (its V is NOT quantised): the reference's own bar
         o1 = oracle.bf16_bits_to_f32(z[key]) if dtype == torch.bfloat16 else oracle.fp16_bits_to_f32(z[key])
         rm1 = float(np.sqrt(np.mean((got - o1) ** 2)))
@@ -257,7 +262,7 @@ def test_hip_graph_capture_of_the_whole_step():
         assert torch.equal(out16, qa.attn_func(q, k, v))
 
 
-@pytest.mark.parametrize("backend", ["eager", "aot_eager"])
+@pytest.mark.parametrize("backend", ["eager", "aot_eager", "inductor"])
 def test_torch_compile_traces_the_ops_as_opaque_calls(backend):
     """inside a user's torch.compile region the custom ops are traced through their fake impls
     (register_fake) and run the same HIP kernels -- results bit-equal to the eager call, for the fp8 and the 16-bit path,
@@ -267,6 +272,21 @@ def test_torch_compile_traces_the_ops_as_opaque_calls(backend):
     def f(q, k, v):
         return qa.fp8_attn_func(q * 1.0, k, v, is_causal=True) + qa.attn_func(q, k, v).to(q.dtype) * 0
 
+    if backend == "inductor":
+        # the reference compiles its wrapper with backend="inductor", fullgraph=True (nn.py:521-539); here Inductor sees the
+        # custom ops as extern calls (register_fake shapes) and fuses the surrounding elementwise work
+        try:
+            cf = torch.compile(f, backend="inductor", dynamic=True, fullgraph=True)
+            q, k, v = (torch.randn(1, 4, 256, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+            got = cf(q, k, v)
+        except Exception as exc:  # no working Triton / C++ toolchain for Inductor on this box: nothing of ours to test
+            if "quantumattention_amd" in str(exc):
+                raise
+            pytest.skip(f"inductor backend unavailable here: {type(exc).__name__}: {str(exc)[:200]}")
+        assert torch.equal(got, f(q, k, v))
+        q, k, v = (torch.randn(1, 4, 384, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+        assert torch.equal(cf(q, k, v), f(q, k, v))
+        return
     cf = torch.compile(f, backend=backend, dynamic=True)
     for S in (256, 384):
         q, k, v = (torch.randn(1, 4, S, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))

@@ -27,6 +27,14 @@ def test_quant_matches_reference_golden_bit_exact(name, scaling):
             x8, s = _native.quant_fp8(x, scaling=scaling, numerics=numerics)
             np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), z[f"s{t}_{m}_{numerics}"].view(np.uint32))
             np.testing.assert_array_equal(bits8(x8), z[f"{t}8_{m}_{numerics}"])
+        # float8_e5m2 (BASELINE config 5's format): the torch.float8_e5m2 fixture of the same compiled numerics
+        x8, s = _native.quant_fp8(x, scaling=scaling, fp8_dtype=torch.float8_e5m2)
+        np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), z[f"s{t}_{m}_e5m2"].view(np.uint32))
+        np.testing.assert_array_equal(bits8(x8), z[f"{t}8_{m}_e5m2"])
+    if m == "head":   # V, head-wise, against the reference's own dynamically_quantize_fp8(v)
+        v8, sv = _native.quant_fp8(from_bits16(z["v"], dtype).cuda(), scaling="head-wise")
+        np.testing.assert_array_equal(sv.cpu().numpy().view(np.uint32), z["sv_head_compiled"].view(np.uint32))
+        np.testing.assert_array_equal(bits8(v8), z["v8_head_compiled"])
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 64, 64), (2, 3, 200, 128), (1, 2, 1000, 256), (1, 1, 4096, 128), (1, 2, 37, 64)])

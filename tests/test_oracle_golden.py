@@ -2,7 +2,10 @@
 
 * quantiser restatement  == reference bytes and scales, bit-exact (both numerics, head/token, bf16/fp16)
 * torch restatement of the literal eager op == reference O1, bit-exact
-* fp64 C oracle (O2) within the reference's own bf16 rounding of O1 (SURVEY.md §8c two-oracle note)
+* fp64 C oracle == the fp64 SDPA fixtures O2 (16-bit V) and O3 (the build's quantised V) to 1e-5: the pin the GPU
+  parity tests stand on; its distance to the reference's literal eager output O1 (which rounds scales, de-quantised q / k
+  and the output to 16 bits, ops.py:76-91) is only REPORTED against the 2^-6 budget (SURVEY.md section 8c two-oracle note)
+* e5m2 quantiser restatement == torch.float8_e5m2 fixture bytes, bit-exact
 """
 import os
 
@@ -97,7 +100,8 @@ def test_torch_port_of_eager_op_bit_exact_to_reference(name, method):
 
 @pytest.mark.parametrize("name", golden_files())
 @pytest.mark.parametrize("method", ["head", "token"])
-def test_c_oracle_within_reference_bf16_rounding(name, method):
+def test_c_oracle_distance_to_reference_eager_output_o1(name, method):
+    """Reported number, not the pin: O1 itself carries 16-bit rounding of the scales, of q / k and of the output."""
     z, (B, H, Sq, Skv, D), fmt = _load(name)
     for causal in (False, True):
         key = f"o1_{method}_{'causal' if causal else 'full'}"
@@ -145,3 +149,46 @@ def test_oracle_lse_and_gqa_consistency():
     s = s.masked_fill(~torch.ones(S, S, dtype=torch.bool).tril(), float("-inf"))
     np.testing.assert_allclose(lse, torch.logsumexp(s, -1).numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(o, (torch.softmax(s, -1) @ tv).numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("method", ["head", "token"])
+def test_c_oracle_pinned_to_fp64_fixtures_o2_o3(name, method):
+    """qo_attention_forward vs the committed fp64 SDPA on the reference's own q8 / k8 / scales --
+    O2 with the 16-bit V, O3 with the reference-quantised (v8, sv) -- at <= 1e-5 (fp32 storage of the fixture)."""
+    z, (B, H, Sq, Skv, D), fmt = _load(name)
+    step = int(z["o23_row_step"][0])
+    checked = 0
+    for causal in (False, True):
+        tag = "causal" if causal else "full"
+        args = (z[f"q8_{method}_compiled"], z[f"k8_{method}_compiled"])
+        scales = (z[f"sq_{method}_compiled"], z[f"sk_{method}_compiled"])
+        if f"o2_{method}_{tag}" in z:
+            o2 = oracle.attention_forward(*args, z["v"], oracle.FMT_E4M3, oracle.FMT_E4M3, fmt, *scales, None,
+                                          scale_mode=method, causal=causal)
+            np.testing.assert_allclose(o2[:, :, ::step], z[f"o2_{method}_{tag}"], rtol=0, atol=1e-5)
+            checked += 1
+        if f"o3_{method}_{tag}" in z:
+            o3 = oracle.attention_forward(*args, z["v8_head_compiled"], oracle.FMT_E4M3, oracle.FMT_E4M3, oracle.FMT_E4M3, *scales,
+                                          z["sv_head_compiled"], scale_mode=method, causal=causal)
+            np.testing.assert_allclose(o3[:, :, ::step], z[f"o3_{method}_{tag}"], rtol=0, atol=1e-5)
+            checked += 1
+    assert checked >= (1 if method == "token" and Sq > 128 and Sq != Skv else 0)
+    if method == "head":
+        assert checked >= 2
+
+
+@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("method", ["head", "token"])
+def test_quantiser_e5m2_and_v_bit_exact(name, method):
+    """e5m2 payloads / scales vs the torch.float8_e5m2 restatement of the compiled numerics, and V quantised head-wise vs the
+    reference's own dynamically_quantize_fp8(v) (the build quantises V too)."""
+    z, _, fmt = _load(name)
+    for t in ("q", "k"):
+        got8, gots = oracle.quantize_fp8(z[t], fmt, method, oracle.FMT_E5M2, "compiled")
+        np.testing.assert_array_equal(gots.view(np.uint32), z[f"s{t}_{method}_e5m2"].view(np.uint32))
+        np.testing.assert_array_equal(got8, z[f"{t}8_{method}_e5m2"])
+    if method == "head":
+        v8, sv = oracle.quantize_fp8(z["v"], fmt, "head", oracle.FMT_E4M3, "compiled")
+        np.testing.assert_array_equal(sv.view(np.uint32), z["sv_head_compiled"].view(np.uint32))
+        np.testing.assert_array_equal(v8, z["v8_head_compiled"])

@@ -2,7 +2,8 @@
   profiles/<name>/kernel_stats.csv   rocprofv3 --kernel-trace --stats (qattn kernels only)
   profiles/<name>/pmc_summary.json   mean counter value per dispatch and kernel, all PMC passes
   profiles/traffic.json              HBM bytes per attention launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-usage: python tools/summarize_profile.py gpurun_out/prof_r01c profiles/r01_final
+usage: python tools/summarize_profile.py gpurun_out/prof_r02_c2 profiles/r02_c2 [B H S D [causal]]
+(the traffic file is written as <dst>/traffic.json; for the headline shape also as profiles/traffic.json)
 """
 import csv
 import glob
@@ -11,6 +12,8 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+shape = tuple(int(x) for x in sys.argv[3:7]) if len(sys.argv) >= 7 else (4, 32, 4096, 128)
+causal = len(sys.argv) >= 8 and sys.argv[7] not in ("0", "false")
 os.makedirs(dst, exist_ok=True)
 csv.field_size_limit(1 << 30)
 
@@ -45,8 +48,9 @@ if attn:
     # FETCH_SIZE / WRITE_SIZE count 64-byte... units of 1 KiB per the guide's rocprofv3 section; FETCH_SIZE under-reports by 2x on gfx950
     fetch = s["FETCH_SIZE"] * 1024 * 2
     write = s["WRITE_SIZE"] * 1024
-    B, H, S, D = 4, 32, 4096, 128
+    B, H, S, D = shape
     out = {
+        "shape": {"B": B, "H": H, "S": S, "D": D, "causal": causal},
         "attn_fwd_hbm_bytes_per_launch": fetch + write,
         "fetch_bytes_x2_corrected": fetch,
         "write_bytes": write,
@@ -54,6 +58,11 @@ if attn:
         "algorithmic_bytes": B * H * S * D * ((2 + 1 + 1 + 2) if fused else (3 + 2)),  # Q (bf16 or fp8) + K + V fp8 + O bf16
         "kernel": key,
     }
-    with open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json"), "w") as f:
+    if causal:   # K/V re-streaming if no query block shared them = (#256-row blocks per head) x 1/2 x (K + V per head)
+        out["kv_restream_bytes_without_l2_reuse"] = B * H * (S // 256) * (S * D * 2) // 2
+    with open(os.path.join(dst, "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
+    if shape == (4, 32, 4096, 128) and not causal:
+        with open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json"), "w") as f:
+            json.dump(out, f, indent=1)
     print(json.dumps(out))
