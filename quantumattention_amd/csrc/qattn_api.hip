@@ -144,6 +144,12 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
             (void)hipMemcpy(r.data(), (const char*)p.dbg_buf + sizeof(unsigned long long) * (1 << 19), sizeof(float) * 4 * rows, hipMemcpyDeviceToHost);
             std::vector<double> R;
             for (long i = 0; i < rows; i++) { const float* d = &r[i * 4]; R.push_back(d[0] * exp2(-(5.0 + (d[1] - d[2]) * d[3]))); }
+            long n24 = 0; int shown = 0;
+            for (long i = 0; i < rows; i++) if (R[i] < 24.0) {
+                n24++;
+                if (shown++ < 6) fprintf(stderr, "[qattn dbg]   row %ld (head %ld, q %ld): R %.2f l %.1f delta %.3f\n", i, i / a.Sq, i % a.Sq, R[i], r[i * 4], (r[i * 4 + 1] - r[i * 4 + 2]) * r[i * 4 + 3]);
+            }
+            fprintf(stderr, "[qattn dbg] rows with R < 24: %ld of %ld = %.2e\n", n24, rows, (double)n24 / rows);
             std::vector<double> Rs = R; std::sort(Rs.begin(), Rs.end());
             fprintf(stderr, "[qattn dbg] R: min %.2f p1 %.2f med %.2f | row0: l %.1f m_true %.3f m_run %.3f c %.4e  row777: l %.1f m_true %.3f m_run %.3f\n", Rs[0], Rs[rows / 100], Rs[rows / 2],
                     r[0], r[1], r[2], r[3], r[777 * 4], r[777 * 4 + 1], r[777 * 4 + 2]);

@@ -227,6 +227,12 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
     pv[w] = (int)b;
 }
 
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 #define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #ifndef QATTN_DEV
 #define QATTN2_STAMP(I) do { } while (0)
@@ -288,18 +294,19 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], pp, st.o[0]);
     if (TWO) st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], ppl, st.o[0]);
     v8i fc = LDSF(vprev + (2 << 11));
-    float mx = fmaxf(fmaxf(sc0[0], sc0[1]), sc0[2]);
+    // (v_max3_f32 through asm: on MFMA results the compiler otherwise adds a canonicalising v_max_f32 x, x, x per chain)
+    float mx = max3_raw(sc0[0], sc0[1], sc0[2]);
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc0[r]), sc0[r + 1]);
-    mx = fmaxf(mx, sc0[15]);
+    for (int r = 3; r < 15; r += 2) mx = max3_raw(mx, sc0[r], sc0[r + 1]);
     QATTN_SLOT_FENCE();
     // slot 1: O1 += V1.P(t-2)            reads: V3            VALU: max over tile 1, group 0
     st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], pp, st.o[1]);
     if (TWO) st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], ppl, st.o[1]);
     v8i fd = LDSF(vprev + (3 << 11));
-    mx = fmaxf(fmaxf(mx, sc1[0]), sc1[1]);
+    mx = max3_raw(mx, sc0[15], sc1[0]);
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sc1[r]), sc1[r + 1]);
+    for (int r = 1; r < 15; r += 2) mx = max3_raw(mx, sc1[r], sc1[r + 1]);
+    mx = max3_raw(mx, sc1[15], sc1[15]);
     QATTN_SM_GROUP(true, sc0, 0, mc, 0, pp[0]);
     QATTN_SLOT_FENCE();
     // slot 2: O2 += V2.P(t-2)            reads: Q k-step 0, K(tile 0, k-step 0)      VALU: group 1
@@ -747,6 +754,14 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
 #else
         const bool mine = __any(peaked) != 0;
 #endif
+        // a wave without a peaked row stores its rows right away (under the other waves' last iterations, as in the unchecked
+        // kernel); only then does it meet the others to learn whether some wave needs the workgroup's help
+        const float sv = p.sv ? p.sv[kv_head] : 1.0f;
+        if (!mine) {
+            store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq);
+            if (p.lse && hh == 0 && qrow < p.Sq)
+                p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
+        }
         if (lane == 0) vote[wave] = mine ? 1u : 0u;
         __syncthreads();   // also: every wave is done with the K/V ring
         unsigned flagged = 0;
@@ -754,13 +769,7 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
         for (int w = 0; w < NW; w++) flagged |= (vote[w] != 0u ? 1u : 0u) << w;
         flagged = __builtin_amdgcn_readfirstlane(flagged);
         const int nf = __builtin_popcount(flagged);
-        if (nf > kMaxRescueWaves) return true;   // many peaked rows: the whole block repeats in two-term mode
-        const float sv = p.sv ? p.sv[kv_head] : 1.0f;
-        if (!mine) {
-            store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq);
-            if (p.lse && hh == 0 && qrow < p.Sq)
-                p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
-        }
+        if (nf > kMaxRescueWaves) return true;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
         if constexpr (!TOKEN && NW == 8) {
             for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u)
                 rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL>(p, smem, kg, vg, q0 - wave * kQPerWave, __builtin_ctz(rest), wave, lane, bh, kv_head, c);

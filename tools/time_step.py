@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from quantumattention_amd import _native
-if os.environ.get("USE_DEV", "1") == "1": _native.LIB_PATH = _native.LIB_PATH.replace(".so", "_dev.so")
+if os.environ.get("QLIB"): _native.LIB_PATH = os.path.abspath(os.environ["QLIB"])
+elif os.environ.get("USE_DEV", "1") == "1": _native.LIB_PATH = _native.LIB_PATH.replace(".so", "_dev.so")
 import quantumattention_amd as qa
 B, H, S, D = 4, 32, 4096, 128
 causal = "--causal" in sys.argv
@@ -23,4 +24,4 @@ with qa.config.patch({"attention.precision": prec}):
     q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q, k, v)
     attn = timeit(lambda: _native.fp8_attention_forward(q8, kf, vf, sq, sk, sv, Hkv=H, Skv=S, out_dtype=torch.bfloat16, is_causal=causal, precision=prec))
     quant = timeit(lambda: _native.quant_qkv_fp8(q, k, v))
-print("env", {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("QATTN_")}, "prec", prec, "| step %.4f ms  attn-only %.4f ms  quant %.4f ms" % (step, attn, quant))
+print("env", {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("QATTN_") or k_ == "QLIB"}, "prec", prec, "| step %.4f ms  attn-only %.4f ms  quant %.4f ms" % (step, attn, quant))
