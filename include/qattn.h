@@ -71,7 +71,8 @@ extern "C" {
  * (src/quantum_attn/tk/attention.py:72,286,318); here P is e4m3, and ONE e4m3 term (3 mantissa bits) is accurate enough
  * only for rows whose weight is spread over many keys:
  *   AUTO     (default) one-term P, checked per row: a 256-row query block in which some row's largest softmax weight
- *            exceeds 1/24 (R = l / p_max < 24) is recomputed with two-term (hi + lo) P before/over its one-term result.
+ *            exceeds 1/24 (R = l / p_max < 24) has those rows' 32-row groups (or, if many, the whole block) recomputed with
+ *            two-term (hi + lo) P.
  *   FAST     one-term P wherever a row sees >= 1024 keys (what other fp8 attention kernels do); no check.
  *   ACCURATE two-term P everywhere (~bf16-P accuracy, 1.5x the matrix work).
  * In every mode query blocks that see fewer than 1024 keys (short sequences, early causal rows) use two-term P. */
@@ -149,7 +150,7 @@ int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S
  *   sm_scale  softmax scale; <= 0 selects 1/sqrt(D) (the reference hard-wires it, tk/attention.py:208-210)
  *   is_causal keep key j <= query i (aten top-left alignment; the reference requires Sq == Skv, tests/test_interface.py:32)
  *   precision QATTN_PRECISION_*
- *   workspace device scratch of qattn_attention_workspace_bytes(B, Hq, Sq) bytes (one word per 256-row query block;
+ *   workspace device scratch of qattn_attention_workspace_bytes(B, Hq, Sq) bytes (one word per 32-row query group;
  *             needed for QATTN_PRECISION_AUTO, may be NULL otherwise)
  * Both GEMMs run on v_mfma_f32_32x32x64_f8f6f4; accumulation, running max/sum and the softmax are fp32.
  */

@@ -71,7 +71,7 @@ struct AttnCall {
     int B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode, is_causal;
     float sm_scale;
     int precision, lse_layout;
-    unsigned* flags;   // nullptr or one word per (b, h, 256-row block) of THIS call
+    unsigned* flags;   // nullptr or one word per (b, h, 32-row group) of THIS call
     const void* q16;   // fused step (else nullptr): bf16 Q, quantised in the kernel from q_amax_bits; sq_out is written
     const unsigned* q_amax_bits;
     float* sq_out;
@@ -226,7 +226,7 @@ extern "C" float qattn_last_attention_ms(void) {
 
 extern "C" size_t qattn_attention_workspace_bytes(int B, int Hq, int Sq) {
     if (B <= 0 || Hq <= 0 || Sq <= 0) return 0;
-    return sizeof(unsigned) * (size_t)B * Hq * ceil_div(Sq, 256);
+    return sizeof(unsigned) * (size_t)B * Hq * ceil_div(Sq, 32);   // one word per 32-row group
 }
 
 extern "C" size_t qattn_lse_row_stride(int Sq, int lse_layout) {

@@ -131,36 +131,6 @@ __device__ __forceinline__ void pv_chunk(const unsigned char* vbuf, const v8i& p
     }
 }
 
-// In-place fix-ups of a finished S^T chunk before its softmax (both rare or cheap, kept out of the hot block):
-// token-wise key scales (inductor/kernels/attention.py:395) and the ragged-tail / causal-diagonal mask.
-template <bool CAUSAL, bool TOKEN>
-__device__ __forceinline__ void prep_scores(v16f& s0, v16f& s1, const AttnParams& p, int k0, int q0, int qrow, int hh,
-                                            const float* skt) {
-    if (TOKEN) {
-#pragma unroll
-        for (int tt = 0; tt < 2; tt++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int kk = k0 + 32 * tt + 8 * j + 4 * hh;  // keys kk..kk+3 live in registers 4j..4j+3 of tile tt
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kk + 3 < p.Skv) w = *reinterpret_cast<const float4*>(skt + kk);
-                else { if (kk < p.Skv) w.x = skt[kk]; if (kk + 1 < p.Skv) w.y = skt[kk + 1]; if (kk + 2 < p.Skv) w.z = skt[kk + 2]; }
-                v16f& sx = tt ? s1 : s0;
-                sx[4 * j + 0] *= w.x; sx[4 * j + 1] *= w.y; sx[4 * j + 2] *= w.z; sx[4 * j + 3] *= w.w;
-            }
-    }
-    const bool need_mask = (k0 + 64 > p.Skv) || (CAUSAL && k0 + 63 > q0);  // wave-uniform
-    if (__builtin_expect(need_mask, 0)) {
-#pragma unroll
-        for (int r = 0; r < 32; r++) {
-            const int key = k0 + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * hh;
-            const bool dead = key >= p.Skv || (CAUSAL && key > qrow);
-            v16f& sx = (r >> 4) ? s1 : s0;
-            sx[r & 15] = dead ? -INFINITY : sx[r & 15];
-        }
-    }
-}
-
 // 4 scores -> 4 exponentials -> one dword of the e4m3 P operand (+ the residual dword when TWO); accumulates the
 // partial row sums in acc[0..3] (FIRST: initialises them).  `seed` only provides the register the first
 // v_cvt_pk_fp8_f32 writes its low half into (its high half is overwritten by the second), saving a v_mov.
@@ -532,150 +502,6 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     for (; t < T; ++t) sync_iter(t);
 }
 
-// Row-group rescue (QATTN_PRECISION_AUTO): recompute the 32 query rows of ONE wave of this
-// workgroup with exact exponentials and two-term P, the key range split over all NW waves (each takes a contiguous run of
-// 64-key chunks, reads the K / V fragments straight from global memory / L2 -- the ring is idle -- and keeps a partial
-// {O, m, l}); the partials are merged pairwise through LDS (three rounds) and wave 0 stores the rows.  Used when at most
-// kMaxRescueWaves waves of a block hold a peaked row: ~0.3 of a block's sweep instead of the 1.5 of repeating the block.
-constexpr int kMaxRescueWaves = 2;
-
-__device__ __forceinline__ v8i gload_frag(const unsigned char* base) {
-    const v4i lo = *reinterpret_cast<const v4i*>(base);
-    const v4i hi = *reinterpret_cast<const v4i*>(base + 512);
-    v8i r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL>
-__device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
-                                            int q0_wg, int fw, int wave, int lane, long bh, long kv_head, float c) {
-    static_assert(NW == 8, "three merge rounds");
-    constexpr int CH = 64 * D, STAGE = 2 * CH, KS = D / 64, MB = D / 32;
-    constexpr int SLOT = (MB * 16 + 2) * 64 * 4;   // one wave's partial {O^T, m, l} in LDS
-    static_assert(4 * SLOT <= kStagesV2 * STAGE, "four partials fit the K/V ring");
-    const int ql = lane & 31, hh = lane >> 5;
-    const int r0 = q0_wg + fw * kQPerWave, row = r0 + ql;
-    const int frag_lane_off = (hh << 10) + (ql << 4);
-    // the rescued wave's Q^T fragments are still parked in its LDS slots
-    const unsigned char* qsrc = smem + kStagesV2 * STAGE + fw * (KS << 11) + frag_lane_off;
-    v8i qf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; s++) qf[s] = lds_read_frag(qsrc + (s << 11));
-    const int n_r = CAUSAL ? min(p.nchunks, (min(r0 + kQPerWave, p.Sq) - 1) / 64 + 1) : p.nchunks;
-    const int per = (n_r + NW - 1) / NW;
-    const int t0 = wave * per, t1 = min(n_r, t0 + per);
-    v16f o[MB];
-#pragma unroll
-    for (int m = 0; m < MB; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
-    float m_run = -1.0e30f, l_run = 0.0f;
-    for (int t = t0; t < t1; t++) {
-        const unsigned char* kc = kg + (long)t * CH + frag_lane_off;
-        const unsigned char* vc = vg + (long)t * CH + frag_lane_off;
-        v16f s0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const v8i ka = gload_frag(kc + ((0 * KS + s) << 11)), kb = gload_frag(kc + ((1 * KS + s) << 11));
-            s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf[s], s0);
-            s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf[s], s1);
-        }
-        v8i vf[MB];
-#pragma unroll
-        for (int m = 0; m < MB; m++) vf[m] = gload_frag(vc + (m << 11));   // in flight under the softmax
-        prep_scores<CAUSAL, false>(s0, s1, p, t * 64, r0, row, hh, nullptr);
-        float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
-        mx = fmaxf(mx, s0[15]);
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
-        {
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        if (__any((mx - m_run) * c > kRescaleThr)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-#pragma unroll
-            for (int m = 0; m < MB; m++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[m][r] *= alpha;
-            l_run *= alpha;
-            m_run = m_new;
-        }
-        const float mc = kPShift - m_run * c;
-        v8i ph, pl;
-        float ls = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 8; w++) {
-            const v16f& sx = w < 4 ? s0 : s1;
-            const int j = w & 3;
-            float e[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) { e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[4 * j + i], c, mc)); ls += e[i]; }
-            int hi = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], 0);
-            hi = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2], e[3], hi);
-            const float h0 = __builtin_amdgcn_cvt_f32_fp8(hi, 0), h1 = __builtin_amdgcn_cvt_f32_fp8(hi, 1);
-            const float h2 = __builtin_amdgcn_cvt_f32_fp8(hi, 2), h3 = __builtin_amdgcn_cvt_f32_fp8(hi, 3);
-            int lo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h0, e[1] - h1, 0);
-            lo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h2, e[3] - h3, lo);
-            ph[w] = hi; pl[w] = lo;
-        }
-        l_run += ls;
-#pragma unroll
-        for (int m = 0; m < MB; m++) {
-            o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], ph, o[m]);
-            o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], pl, o[m]);
-        }
-    }
-    // ---- merge the NW partials pairwise through LDS: {4..7} -> {0..3}, {2,3} -> {0,1}, {1} -> {0}
-    float* slots = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int half = NW / 2; half >= 1; half >>= 1) {
-        if (wave >= half && wave < 2 * half) {
-            float* d = slots + (wave - half) * (SLOT / 4);
-#pragma unroll
-            for (int m = 0; m < MB; m++)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++)
-                    *reinterpret_cast<v4f*>(d + ((m * 4 + r4) * 64 + lane) * 4) = v4f{o[m][4 * r4], o[m][4 * r4 + 1], o[m][4 * r4 + 2], o[m][4 * r4 + 3]};
-            d[MB * 16 * 64 + lane] = m_run;
-            d[(MB * 16 + 1) * 64 + lane] = l_run;
-        }
-        __syncthreads();
-        if (wave < half) {
-            const float* d = slots + wave * (SLOT / 4);
-            const float m_b = d[MB * 16 * 64 + lane], l_b = d[(MB * 16 + 1) * 64 + lane];
-            const float m_new = fmaxf(m_run, m_b);
-            const float fa = __builtin_amdgcn_exp2f((m_run - m_new) * c), fb = __builtin_amdgcn_exp2f((m_b - m_new) * c);
-#pragma unroll
-            for (int m = 0; m < MB; m++)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const v4f ob = *reinterpret_cast<const v4f*>(d + ((m * 4 + r4) * 64 + lane) * 4);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) o[m][4 * r4 + i] = o[m][4 * r4 + i] * fa + ob[i] * fb;
-                }
-            l_run = l_run * fa + l_b * fb;
-            m_run = m_new;
-        }
-        __syncthreads();
-    }
-    if (wave == 0) {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-        const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        const float sv = p.sv ? p.sv[kv_head] : 1.0f;
-        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + row, hh, row < p.Sq);
-        if (p.lse && hh == 0 && row < p.Sq)
-            p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
-    }
-}
-
 // One pass of a wave over its KV range with P in TWO (hi + lo) or one term, BYTE-exponential or exact, followed by the
 // row sums.  Returns true when `check_peaked` is set and some row of the WORKGROUP turned out to be peaked (its largest
 // softmax weight 1 / R exceeds 1 / peak_r0): nothing has been stored then and the caller repeats the block in two-term
@@ -771,8 +597,13 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
         const int nf = __builtin_popcount(flagged);
         if (nf > kMaxRescueWaves) return true;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
         if constexpr (!TOKEN && NW == 8) {
-            for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u)
-                rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL>(p, smem, kg, vg, q0 - wave * kQPerWave, __builtin_ctz(rest), wave, lane, bh, kv_head, c);
+            for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
+                // the rescued wave's Q^T fragments are still parked in its LDS slots; the K/V ring is idle and holds the merge
+                const int fw = __builtin_ctz(rest);
+                const unsigned char* qsrc = smem + kStagesV2 * 2 * 64 * D + fw * ((D / 64) << 11) + ((lane >> 5) << 10) + ((lane & 31) << 4);
+                rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL, false>(p, smem, kg, vg, q0 - wave * kQPerWave + fw * kQPerWave, wave, lane, bh, kv_head, c,
+                                                                nullptr, [&](int s_) { return lds_read_frag(qsrc + (s_ << 11)); });
+            }
         } else {
             if (nf > 0) return true;
         }

@@ -9,9 +9,11 @@
 // (48 KiB LDS), and a CU holds THREE independent workgroups: each SIMD interleaves three waves that belong to different
 // workgroups, hence are never phase-aligned, and one wave's softmax hides under the other two's MFMAs.
 // Templated on the head dimension: the whole forward for D = 64 / 256 and the D = 128 cases the hand-scheduled kernel does
-// not cover (token-wise scales under the causal mask).  Precision modes: the one-term launch records,
-// per (head, 256-row block), whether a row ended peaked (R = l / p_max < peak_r0) in p.flags; a second launch of the exact
-// two-term variant over the same blocks recomputes exactly the flagged ones (unflagged workgroups return at once).
+// not cover (token-wise scales).  Precision modes: the one-term launch records, per (head, 32-row
+// group = one wave's rows), whether a row ended peaked (R = l / p_max < peak_r0) in p.flags.  Two more launches follow:
+// rescue_groups_kernel recomputes the flagged groups of every 256-row block that has at most kMaxRescueWaves of them
+// (split-K over 8 waves, as inside the D = 128 kernel); the exact two-term variant of this kernel redoes the blocks with
+// more.  Workgroups with nothing to do return at once.
 #include "qattn_attn.h"
 
 namespace qattn {
@@ -42,9 +44,10 @@ template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE>
 __global__ __launch_bounds__((V4Shape<D, (BYTE && !TOKEN)>::NW * 64), (V4Shape<D, (BYTE && !TOKEN)>::WPS))
 void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, const int mode) {
     const int two = mode & 1;            // exact kernels: hi + lo (two-term) P
-    const bool only_flagged = mode & 2;  // rescue launch: recompute only the blocks the one-term launch flagged
+    const bool only_flagged = mode & 2;  // redo launch: only the 256-row blocks with more than kMaxRescueWaves flagged groups
+    const int redo_above = (mode & 4) ? 0 : kMaxRescueWaves;  // (mode & 4: no rescue launch ran, every flagged block is redone)
     constexpr int NW = V4Shape<D, (BYTE && !TOKEN)>::NW, kQPerWG4 = NW * kQPerWave;
-    constexpr int CH = 64 * D, STAGE = 2 * CH, MB = D / 32, KS = D / 64;
+    constexpr int CH = 64 * D, STAGE = 2 * CH + (TOKEN ? 256 : 0), MB = D / 32, KS = D / 64;   // token-wise: + the chunk's 64 key scales
     constexpr int RK = CH / (NW * 1024);   // 1 KiB DMA pieces per wave for the K (and for the V) part of a stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -58,13 +61,20 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
     const int q0_wg = qb * kQPerWG4, q0 = q0_wg + wave * kQPerWave, qrow = q0 + ql;
     const long bh = (long)b * p.Hq + h;
-    unsigned* flag = p.flags ? p.flags + bh * ((p.Sq + 255) >> 8) + (q0_wg >> 8) : nullptr;
-    if (only_flagged && *flag == 0u) return;  // workgroup-uniform
+    const int ng = (p.Sq + 31) >> 5;          // 32-row groups per head
+    unsigned* flag = p.flags ? p.flags + bh * ng + (q0 >> 5) : nullptr;   // this wave's group
+    if (only_flagged) {  // workgroup-uniform: count the flagged groups of the 256-row block these rows belong to
+        const int g0 = (q0_wg >> 8) << 3;
+        int nf = 0;
+        for (int g = g0; g < min(g0 + 8, ng); g++) nf += p.flags[bh * ng + g] != 0u;
+        if (nf <= redo_above) return;
+    }
     const unsigned char* kg_w = p.k + kv_head * (long)p.nchunks * CH + (wave << 10);
     const unsigned char* vg_w = p.v + kv_head * (long)p.nchunks * CH + (wave << 10);
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + kQPerWG4, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
 
+    const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
     // stage(t) = {K chunk t, V chunk t} -> slot t & 1; every wave copies 2*RK x 1 KiB of it by LDS-DMA
     const unsigned lane16 = (unsigned)lane << 4;
     unsigned coff = 0, slot_next = 0;
@@ -76,6 +86,13 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
                                              (__attribute__((address_space(3))) void*)(dst + r * (NW * 1024)), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (coff + lane16 + r * (NW * 1024))),
                                              (__attribute__((address_space(3))) void*)(dst + CH + r * (NW * 1024)), 16, 0, 0);
+        }
+        if (TOKEN && wave == 0) {
+            // the chunk's 64 per-key scales ride along with the stage (one 4-byte LDS-DMA piece per lane): read from global
+            // memory right before their use they exposed a load latency per chunk (1.20 ms at the C2 shape)
+            const int key = min((int)(coff / CH) * 64 + lane, p.Skv - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(skt + key),
+                                             (__attribute__((address_space(3))) void*)(smem + slot_next + 2 * CH), 4, 0, 0);
         }
         coff += CH;
         slot_next ^= STAGE;
@@ -99,7 +116,6 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     float c;
     if (TOKEN) c = p.sm_log2e * (qrow < p.Sq ? p.sq[((long)b * p.Hq + h) * p.Sq + qrow] : 1.0f);
     else c = p.sm_log2e * p.sq[(long)b * p.Hq + h] * p.sk[kv_head];
-    const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
 
     v16f o[MB];
 #pragma unroll
@@ -149,10 +165,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
             for (int tt = 0; tt < 2; tt++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int kk = k0 + 32 * tt + 8 * j + 4 * hh;
-                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (kk + 3 < p.Skv) w = *reinterpret_cast<const float4*>(skt + kk);
-                    else { if (kk < p.Skv) w.x = skt[kk]; if (kk + 1 < p.Skv) w.y = skt[kk + 1]; if (kk + 2 < p.Skv) w.z = skt[kk + 2]; }
+                    const float4 w = *reinterpret_cast<const float4*>(kbuf - frag_lane_off + 2 * CH + (32 * tt + 8 * j + 4 * hh) * 4);
                     v16f& sx = tt ? s1 : s0;
                     sx[4 * j + 0] *= w.x; sx[4 * j + 1] *= w.y; sx[4 * j + 2] *= w.z; sx[4 * j + 3] *= w.w;
                 }
@@ -259,9 +272,9 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     }
     constexpr float SHIFT = BYTE ? kPShiftByte : kPShift;
     if (p.peak_r0 > 0.0f && !two && !only_flagged) {
-        // one-term launch: R = l' / p'_max is the inverse of the row's largest softmax weight; a peaked row flags its block
+        // one-term launch: R = l' / p'_max is the inverse of the row's largest softmax weight; a peaked row flags its group
         const bool peaked = qrow < p.Sq && l_tot * __builtin_amdgcn_exp2f(-(SHIFT + (m_true - m_run) * c)) < p.peak_r0;
-        if (__any(peaked) && lane == 0) *flag = 1u;
+        if (__any(peaked) && lane == 0 && q0 < p.Sq) *flag = 1u;
     }
     const float sv = p.sv ? p.sv[kv_head] : 1.0f;
     const float inv = sv / l_tot;
@@ -276,7 +289,7 @@ static int launch_v4_one(const AttnParams& p, int row_lo, int row_hi, int mode, 
     const int qb_lo = row_lo / ROWS, qb_n = ceil_div(min(row_hi, p.Sq), ROWS) - qb_lo;
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
-    const size_t lds = (size_t)kStages4 * 2 * 64 * D + (size_t)NW * kQPerWave * D;  // K/V ring + parked Q^T fragments
+    const size_t lds = (size_t)kStages4 * (2 * 64 * D + (TOKEN ? 256 : 0)) + (size_t)NW * kQPerWave * D;  // K/V ring (+ key scales) + parked Q^T fragments
     auto kern = attn_fwd_kernel_v4<D, FMT, FMT, CAUSAL, TOKEN, BYTE>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n, mode);
@@ -297,6 +310,77 @@ static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode,
 #undef QATTN_V4
 }
 
+// Rescue launch: one 8-wave workgroup per 256-row block; the flagged 32-row groups of a block with at most kMaxRescueWaves of
+// them are recomputed by rescue_rows (qattn_attn.h), the Q^T fragments fetched from the row-major q8 tensor.
+template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
+__global__ __launch_bounds__(512, 2) void rescue_groups_kernel(const AttnParams p, const int blk_lo, const int blk_n) {
+    constexpr int CH = 64 * D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+    int head, blk;
+    map_block(p, blockIdx.x, blk_n, false, head, blk);
+    blk += blk_lo;
+    const int b = head / p.Hq, h = head % p.Hq;
+    const long bh = (long)b * p.Hq + h;
+    const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+    const int ng = (p.Sq + 31) >> 5;
+    unsigned flagged = 0;
+    for (int g = 0; g < 8; g++)
+        if (blk * 8 + g < ng && p.flags[bh * ng + blk * 8 + g] != 0u) flagged |= 1u << g;
+    flagged = __builtin_amdgcn_readfirstlane(flagged);
+    if (flagged == 0u || __builtin_popcount(flagged) > kMaxRescueWaves) return;   // nothing to do / redone by the two-term launch
+    const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
+    const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
+    const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
+    for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
+        const int r0 = blk * 256 + __builtin_ctz(rest) * kQPerWave, row = r0 + ql;
+        const bool qvalid = row < p.Sq;
+        float c;
+        if (TOKEN) c = p.sm_log2e * (qvalid ? p.sq[bh * p.Sq + row] : 1.0f);
+        else c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
+        const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? row : 0)) * D) + hh * 32;
+        auto qfrag = [&](int s_) {
+            v4i lo = *reinterpret_cast<const v4i*>(qp + s_ * 64);
+            v4i hi = *reinterpret_cast<const v4i*>(qp + s_ * 64 + 16);
+            if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
+            return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        rescue_rows<D, 8, QK_FMT, V_FMT, CAUSAL, TOKEN>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, skt, qfrag);
+    }
+}
+
+template <int D, int FMT, bool CAUSAL, bool TOKEN>
+static int launch_rescue_one(const AttnParams& p, int row_lo, hipStream_t st) {
+    const int blk_lo = row_lo / 256, blk_n = ceil_div(p.Sq, 256) - blk_lo;
+    if (blk_n <= 0) return QATTN_OK;
+    const size_t lds = 4 * (size_t)rescue_slot_bytes<D>();
+    auto kern = rescue_groups_kernel<D, FMT, FMT, CAUSAL, TOKEN>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(p.B * p.Hq * blk_n), dim3(512), lds, st, p, blk_lo, blk_n);
+    return QATTN_OK;
+}
+
+template <int D>
+static int launch_rescue_d(const AttnParams& p, int fmt, int causal, int scale_mode, int row_lo, hipStream_t st) {
+    const bool tok = scale_mode == QATTN_SCALE_TOKEN;
+#define QATTN_RS(F, C, T) return launch_rescue_one<D, F, C, T>(p, row_lo, st)
+    if (fmt == QATTN_FMT_E4M3) {
+        if (causal) { if (tok) QATTN_RS(QATTN_FMT_E4M3, true, true); else QATTN_RS(QATTN_FMT_E4M3, true, false); }
+        else { if (tok) QATTN_RS(QATTN_FMT_E4M3, false, true); else QATTN_RS(QATTN_FMT_E4M3, false, false); }
+    } else {
+        if (causal) { if (tok) QATTN_RS(QATTN_FMT_E5M2, true, true); else QATTN_RS(QATTN_FMT_E5M2, true, false); }
+        else { if (tok) QATTN_RS(QATTN_FMT_E5M2, false, true); else QATTN_RS(QATTN_FMT_E5M2, false, false); }
+    }
+#undef QATTN_RS
+}
+
+template <int D>
+static int launch_rescue_head(const AttnParams& p, int fmt, int causal, int row_lo, hipStream_t st) {  // head-wise scales only
+    if (fmt == QATTN_FMT_E4M3) return causal ? launch_rescue_one<D, QATTN_FMT_E4M3, true, false>(p, row_lo, st) : launch_rescue_one<D, QATTN_FMT_E4M3, false, false>(p, row_lo, st);
+    return causal ? launch_rescue_one<D, QATTN_FMT_E5M2, true, false>(p, row_lo, st) : launch_rescue_one<D, QATTN_FMT_E5M2, false, false>(p, row_lo, st);
+}
+
 template <int D>
 static int launch_v4_full_d(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) {
     // leading rows (a multiple of 256) that run two-term P from the start: all of them (QATTN_PRECISION_ACCURATE) or those
@@ -310,14 +394,22 @@ static int launch_v4_full_d(const AttnParams& p, int fmt, int causal, int scale_
     const bool rescue = p.peak_r0 > 0.0f && rows_two < p.Sq;
     if (rescue) {
         if (!p.flags) return QATTN_ERR_WORKSPACE;
-        if (hipMemsetAsync(p.flags, 0, sizeof(unsigned) * (size_t)p.B * p.Hq * ceil_div(p.Sq, 256), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+        if (hipMemsetAsync(p.flags, 0, sizeof(unsigned) * (size_t)p.B * p.Hq * ceil_div(p.Sq, 32), st) != hipSuccess) return QATTN_ERR_LAUNCH;
     }
     int rc = QATTN_OK;
     if (rows_two < p.Sq)
         rc = byte_exp ? launch_v4_d<D, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
                       : launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
     if (rc == QATTN_OK && rows_two > 0) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, 0, rows_two, 1, st);
-    if (rc == QATTN_OK && rescue) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 3, st);
+    // flagged 32-row groups: rescued one by one where a 256-row block has few of them, else the block is redone
+    // (D = 256 with token-wise scales: the rescue loop does not fit 256 registers beside 128 of O^T -- every flagged block is redone)
+    const bool group_rescue = !(D == 256 && scale_mode == QATTN_SCALE_TOKEN);
+    if constexpr (D != 256) {
+        if (rc == QATTN_OK && rescue) rc = launch_rescue_d<D>(p, fmt, causal, scale_mode, rows_two, st);
+    } else {
+        if (rc == QATTN_OK && rescue && group_rescue) rc = launch_rescue_head<D>(p, fmt, causal, rows_two, st);
+    }
+    if (rc == QATTN_OK && rescue) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, group_rescue ? 3 : 7, st);
     return rc;
 }
 

@@ -313,7 +313,7 @@ def test_c_abi_error_codes_instead_of_exceptions():
                                              P(ws) if ws is not None else None, ctypes.c_size_t(ws_bytes), None)
 
     assert attn() == 0 and attn(precision=1, ws=None, ws_bytes=0) == 0 and attn(precision=2, ws=None, ws_bytes=0) == 0
-    assert attn(ws=None, ws_bytes=0) == -4 and attn(ws_bytes=4) == -4       # QATTN_PRECISION_AUTO needs its flag words
+    assert attn(ws=None, ws_bytes=0) == -4 and attn(ws_bytes=8) == -4       # QATTN_PRECISION_AUTO needs its flag words (2 heads x 2 groups)
     assert attn(precision=3) == -1 and attn(lse_layout=2) == -1
     assert attn(D=96) == -2 and L.qattn_strerror(-2) is not None       # head_dim not in {64,128,256} (nn.py:45-49)
     assert attn(Hq=3, Hkv=2) == -2                                     # Hq % Hkv != 0
