@@ -15,11 +15,23 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libqattn_hip.so")
 SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip"]
+# (source, extra flags, object name): the two big kernel files are compiled once per operand format / head dimension so that
+# the build runs in parallel (the longest single translation unit sets the wall time)
+# (a unit with a define is compiled through a two-line wrapper file named after the unit, so that -save-temps leaves one .s
+# per unit for tests/test_kernel_resources.py)
+UNITS = [
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0"], "qattn_attn_v2_e4m3"),
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1"], "qattn_attn_v2_e5m2"),
+    ("qattn_attn_v4.hip", ["QATTN_ONLY_D 64"], "qattn_attn_v4_d64"),
+    ("qattn_attn_v4.hip", ["QATTN_ONLY_D 128"], "qattn_attn_v4_d128"),
+    ("qattn_attn_v4.hip", ["QATTN_ONLY_D 256"], "qattn_attn_v4_d256"),
+    ("qattn_attn16.hip", [], "qattn_attn16"),
+    ("qattn_quant.hip", [], "qattn_quant"),
+    ("qattn_api.hip", [], "qattn_api"),
+]
 # `--dev` builds libqattn_hip_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
 # QATTN_* environment switches.  The product library contains none of them.
-DEV_SOURCES = []
 ARCH = "gfx950"
-EXTRA_FLAGS = {}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-ffp-contract=off", "-Wall", "-Wno-unused-command-line-argument", "-Wno-unused-value", "-Wno-pass-failed"]
 
@@ -46,12 +58,18 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "qattn.h"))
     objs, jobs = [], []
-    for src in SOURCES + (DEV_SOURCES if dev else []):
+    for src, defines, name in UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(build_dir, src.replace(".hip", ".o"))
+        o = os.path.join(build_dir, name + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + (["-DQATTN_DEV"] if dev else []) + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+        if force or _stale(o, [s] + headers) or (save_temps and not os.path.exists(os.path.join(build_dir, name + "-hip-amdgcn-amd-amdhsa-gfx950.s"))):
+            unit = s
+            if defines:
+                unit = os.path.join(build_dir, name + ".hip")
+                text = "".join(f"#define {d}\n" for d in defines) + f'#include "{s}"\n'
+                if not os.path.exists(unit) or open(unit).read() != text:
+                    open(unit, "w").write(text)
+            cmd = [hipcc] + FLAGS + (["-DQATTN_DEV"] if dev else []) + ["-c", unit, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)
@@ -59,7 +77,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=build_dir)
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)

@@ -20,13 +20,13 @@ namespace {
 //   QATTN_EXACT_EXP=1       exact v_exp_f32 + RNE conversion instead of the byte exponential
 //   QATTN_V2_WAVES / QATTN_V2_LDS / QATTN_V2_DBG / QATTN_TWO_TERM_KEYS / QATTN_PEAK_R0 / QATTN_NO_Q_FUSION
 struct DevEnv {
-    int variant, exact_exp, waves, lds, dbg, two_term_keys, no_q_fusion;
+    int variant, exact_exp, waves, lds, dbg, two_term_keys, no_q_fusion, causal_group;
     float peak_r0;
     DevEnv() {
         auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
         variant = geti("QATTN_KERNEL_VARIANT", 2); exact_exp = geti("QATTN_EXACT_EXP", 0); waves = geti("QATTN_V2_WAVES", 8);
         lds = geti("QATTN_V2_LDS", 0); dbg = geti("QATTN_V2_DBG", 0); two_term_keys = geti("QATTN_TWO_TERM_KEYS", kTwoTermKeys);
-        no_q_fusion = geti("QATTN_NO_Q_FUSION", 0);
+        no_q_fusion = geti("QATTN_NO_Q_FUSION", 0); causal_group = geti("QATTN_CAUSAL_GROUP", 0);
         const char* e = getenv("QATTN_PEAK_R0");
         peak_r0 = e ? (float)atof(e) : kPeakR0;
     }
@@ -100,6 +100,9 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.nchunks = ceil_div(a.Skv, 64);
     p.out_fmt = a.out_fmt;
     p.xcd_remap = ((a.B * a.Hq) % 8 == 0) ? 1 : 0;
+    p.causal_group = 1;
+    for (int g = kCausalHeadGroup; g > 1; g >>= 1)
+        if (p.xcd_remap && ((a.B * a.Hq) >> 3) % g == 0) { p.causal_group = g; break; }
     const float sm = a.sm_scale > 0.0f ? a.sm_scale : 1.0f / sqrtf((float)a.D);
     p.sm_log2e = sm * 1.4426950408889634f;
     p.precision = a.precision;
@@ -126,6 +129,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
         (void)hipMemsetAsync(dbg_dev, 0, sizeof(unsigned long long) * 2 * n_dbg_waves, st);
     }
     if (e.variant == 4) use_v2 = false;
+    if (e.causal_group > 0 && p.xcd_remap && ((a.B * a.Hq) >> 3) % e.causal_group == 0) p.causal_group = e.causal_group;
 #endif
     const bool prof = ds != nullptr;
     if (prof) (void)hipEventRecord(ds->prof[0], st);
@@ -153,6 +157,28 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
             std::vector<double> Rs = R; std::sort(Rs.begin(), Rs.end());
             fprintf(stderr, "[qattn dbg] R: min %.2f p1 %.2f med %.2f | row0: l %.1f m_true %.3f m_run %.3f c %.4e  row777: l %.1f m_true %.3f m_run %.3f\n", Rs[0], Rs[rows / 100], Rs[rows / 2],
                     r[0], r[1], r[2], r[3], r[777 * 4], r[777 * 4 + 1], r[777 * 4 + 2]);
+        }
+        if (printed == 3 && (p.dbg & 8)) {   // block timeline (QATTN_V2_DBG=24): realtime stamps per wave, 10 ns ticks
+            std::vector<unsigned long long> tl(4 * n_dbg_waves);
+            (void)hipMemcpy(tl.data(), p.dbg_buf + (1 << 18), sizeof(unsigned long long) * 4 * n_dbg_waves, hipMemcpyDeviceToHost);
+            std::vector<double> pro, swp, epi, tot, skew;
+            unsigned long long first = ~0ull, last = 0;
+            for (long b = 0; b < n_dbg_waves / p.waves; b++) {
+                unsigned long long e0 = ~0ull, x1 = 0;
+                for (int w = 0; w < p.waves; w++) {
+                    const unsigned long long* t = &tl[4 * (b * p.waves + w)];
+                    if (!t[3]) continue;
+                    pro.push_back((t[1] - t[0]) * 0.01); swp.push_back((t[2] - t[1]) * 0.01); epi.push_back((t[3] - t[2]) * 0.01);
+                    e0 = std::min(e0, t[0]); x1 = std::max(x1, t[3]);
+                    first = std::min(first, t[0]); last = std::max(last, t[3]);
+                }
+                if (x1) tot.push_back((x1 - e0) * 0.01);
+            }
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+            const double span = (last - first) * 0.01, blocks = (double)tot.size(), busy = med(tot) * blocks / 256.0;
+            fprintf(stderr, "[qattn dbg] timeline (us, medians over waves): prologue %.2f | sweep %.2f | epilogue+exit %.2f | block %.2f ; kernel span %.1f us, "
+                            "blocks %.0f -> %.1f blocks per CU x block = %.1f us (%.0f %% of the span)\n",
+                    med(pro), med(swp), med(epi), med(tot), span, blocks, blocks / 256.0, busy, 100.0 * busy / span);
         }
         if (printed++ == 3) {
             std::vector<unsigned long long> h(2 * n_dbg_waves);

@@ -32,6 +32,7 @@ struct AttnParams {
     int nchunks;     // 64-key chunks per head
     int out_fmt;
     int xcd_remap;   // 1: each XCD gets a contiguous range of heads
+    int causal_group;  // causal: heads per longest-first group within an XCD (1 = head after head)
     float sm_log2e;  // sm_scale * log2(e)
     int exact_exp;   // 1: v_exp_f32 + RNE fp8 conversion everywhere (no byte-exponential fast path)
     int precision;   // QATTN_PRECISION_*
@@ -123,11 +124,22 @@ __device__ inline void wait_vmcnt() {
 }
 
 // block -> (head, query block).  Blocks b and b+8 share an XCD (round-robin dispatch; a speed assumption only):
-// each XCD gets a contiguous range of heads so the 1-2 heads it works on keep their K/V in its private 4 MiB L2.
+// each XCD gets a contiguous range of heads so the heads it works on keep their K/V in its private 4 MiB L2.
+// Causal: query blocks differ 16:1 in work, so within an XCD the heads are taken in groups of kCausalHeadGroup and a
+// group's blocks are issued heaviest first ACROSS its heads (longest-processing-time order: the launch ends on the lightest
+// blocks instead of on a late heavy one); 4 heads x (K + V) = 4 MiB at S = 4096, D = 128 still fit the XCD's L2.
+constexpr int kCausalHeadGroup = 4;
 __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool causal, int& head, int& qb) {
     if (p.xcd_remap) {
-        const int xcd = bid & 7, idx = bid >> 3;
-        head = xcd * ((p.B * p.Hq) >> 3) + idx / nqb;
+        const int xcd = bid & 7, idx = bid >> 3, hpx = (p.B * p.Hq) >> 3;
+        const int G = p.causal_group;
+        if (causal && G > 1) {
+            const int per = G * nqb, grp = idx / per, r = idx % per;
+            head = xcd * hpx + grp * G + r % G;
+            qb = nqb - 1 - r / G;
+            return;
+        }
+        head = xcd * hpx + idx / nqb;
         qb = idx % nqb;
     } else {
         head = bid / nqb;
@@ -325,9 +337,30 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
     }
 }
 
-bool attn_v2_covers(int D, int causal, int scale_mode);
-int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
-int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st);
+// kernel-file entry points (one translation unit per operand format / head dimension, see build.py)
+int launch_attn_v2_e4m3(const AttnParams& p, int causal, int scale_mode, hipStream_t st);
+int launch_attn_v2_e5m2(const AttnParams& p, int causal, int scale_mode, hipStream_t st);
+int launch_attn_v4_d64(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
+int launch_attn_v4_d128(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
+int launch_attn_v4_d256(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
+
+// true when the hand-scheduled kernel (qattn_attn_v2.hip) covers the case: D = 128 with head-wise scales.  Token-wise scales
+// need 32 more registers per chunk for the per-key factors, which does not fit 256 registers at two waves per SIMD next
+// to the two-term pass: those calls run on the templated kernel (qattn_attn_v4.hip).
+inline bool attn_v2_covers(int D, int causal, int scale_mode) {
+    (void)causal;
+    return D == 128 && scale_mode == QATTN_SCALE_HEAD;
+}
+inline int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
+    if (!attn_v2_covers(D, causal, scale_mode)) return QATTN_ERR_UNSUPPORTED_DIM;
+    return fmt == QATTN_FMT_E4M3 ? launch_attn_v2_e4m3(p, causal, scale_mode, st) : launch_attn_v2_e5m2(p, causal, scale_mode, st);
+}
+inline int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
+    if (D == 64) return launch_attn_v4_d64(p, fmt, causal, scale_mode, st);
+    if (D == 128) return launch_attn_v4_d128(p, fmt, causal, scale_mode, st);
+    if (D == 256) return launch_attn_v4_d256(p, fmt, causal, scale_mode, st);
+    return QATTN_ERR_UNSUPPORTED_DIM;
+}
 
 
 }  // namespace qattn

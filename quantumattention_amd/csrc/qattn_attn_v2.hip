@@ -543,6 +543,8 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
             const long wid = (long)blockIdx.x * NW + wave;
             p.dbg_buf[2 * wid] = t1 - dbg_t0;
             p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
+            p.dbg_buf[(1 << 18) + 4 * wid + 1] = dbg_r0;   // timeline: sweep start / end (100 MHz ticks)
+            p.dbg_buf[(1 << 18) + 4 * wid + 2] = r1;
             if ((ABL & 16) && wid < 64) {
                 unsigned long long* segout = p.dbg_buf + 2 * (1 << 19) + wid * 8;
                 for (int i = 0; i < 6; i++) segout[i] = st.seg[i];
@@ -729,13 +731,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     // one-term pass stays live in registers across the two-term loop (and vice versa).
     bool two = qb < p.n_two;  // workgroup-uniform
     int tid = threadIdx.x;
+#ifdef QATTN_DEV
+    const unsigned long long dbg_entry = (p.dbg & 16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto dbg_exit = [&]() {
+        if ((p.dbg & 16) && (threadIdx.x & 63) == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row stores have left
+            const long wid = (long)blockIdx.x * NW + (threadIdx.x >> 6);
+            p.dbg_buf[(1 << 18) + 4 * wid + 0] = dbg_entry;
+            p.dbg_buf[(1 << 18) + 4 * wid + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+#else
+    auto dbg_exit = [&]() {};
+#endif
     for (;;) {
         asm volatile("" : "+v"(tid));
         if (two) {
             block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, false);
+            dbg_exit();
             return;
         }
-        if (!block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, p.peak_r0 > 0.0f)) return;
+        if (!block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, p.peak_r0 > 0.0f)) { dbg_exit(); return; }
         two = true;  // a row of this block is peaked: every wave is past the vote barrier, hence done with the K/V ring
     }
 }
@@ -792,26 +808,19 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     return byte_exp ? launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true>(p, st) : launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false>(p, st);
 }
 
-template <int D, int NW>
-static int launch_attn_v2_d(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (fmt == QATTN_FMT_E4M3) return causal ? launch_attn_v2_t<D, NW, QATTN_FMT_E4M3, true>(p, scale_mode, st) : launch_attn_v2_t<D, NW, QATTN_FMT_E4M3, false>(p, scale_mode, st);
-    return causal ? launch_attn_v2_t<D, NW, QATTN_FMT_E5M2, true>(p, scale_mode, st) : launch_attn_v2_t<D, NW, QATTN_FMT_E5M2, false>(p, scale_mode, st);
-}
-
-// true when this file's hand-scheduled kernel covers the case: D = 128 with head-wise scales.  Token-wise scales need 32
-// more registers per chunk for the per-key factors, which does not fit 256 registers at two waves per SIMD next to the
-// two-term pass: those calls run on the templated kernel (qattn_attn_v4.hip).
-bool attn_v2_covers(int D, int causal, int scale_mode) {
-    (void)causal;
-    return D == 128 && scale_mode == QATTN_SCALE_HEAD;
-}
-
-int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (!attn_v2_covers(D, causal, scale_mode)) return QATTN_ERR_UNSUPPORTED_DIM;
+// One translation unit per operand format (build.py: -DQATTN_ONLY_FMT=0|1); without the macro the file provides both.
+template <int FMT>
+static int launch_attn_v2_fmt(const AttnParams& p, int causal, int scale_mode, hipStream_t st) {
 #ifdef QATTN_DEV
-    if (p.waves == 4) return launch_attn_v2_d<128, 4>(p, fmt, causal, scale_mode, st);
+    if (p.waves == 4) return causal ? launch_attn_v2_t<128, 4, FMT, true>(p, scale_mode, st) : launch_attn_v2_t<128, 4, FMT, false>(p, scale_mode, st);
 #endif
-    return launch_attn_v2_d<128, 8>(p, fmt, causal, scale_mode, st);
+    return causal ? launch_attn_v2_t<128, 8, FMT, true>(p, scale_mode, st) : launch_attn_v2_t<128, 8, FMT, false>(p, scale_mode, st);
 }
+#if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 0
+int launch_attn_v2_e4m3(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E4M3>(p, causal, scale_mode, st); }
+#endif
+#if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 1
+int launch_attn_v2_e5m2(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E5M2>(p, causal, scale_mode, st); }
+#endif
 
 }  // namespace qattn

@@ -414,11 +414,16 @@ static int launch_v4_full_d(const AttnParams& p, int fmt, int causal, int scale_
 }
 
 // The whole forward on the templated kernel: D = 64 / 256, and D = 128 where qattn_attn_v2.hip does not apply.
-int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
-    if (D == 64) return launch_v4_full_d<64>(p, fmt, causal, scale_mode, st);
-    if (D == 128) return launch_v4_full_d<128>(p, fmt, causal, scale_mode, st);
-    if (D == 256) return launch_v4_full_d<256>(p, fmt, causal, scale_mode, st);
-    return QATTN_ERR_UNSUPPORTED_DIM;
-}
+// One translation unit per head dimension (build.py compiles this file three times with -DQATTN_ONLY_D=64|128|256, which keeps
+// the build parallel); without the macro the file provides all three.
+#if !defined(QATTN_ONLY_D) || QATTN_ONLY_D == 64
+int launch_attn_v4_d64(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) { return launch_v4_full_d<64>(p, fmt, causal, scale_mode, st); }
+#endif
+#if !defined(QATTN_ONLY_D) || QATTN_ONLY_D == 128
+int launch_attn_v4_d128(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) { return launch_v4_full_d<128>(p, fmt, causal, scale_mode, st); }
+#endif
+#if !defined(QATTN_ONLY_D) || QATTN_ONLY_D == 256
+int launch_attn_v4_d256(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) { return launch_v4_full_d<256>(p, fmt, causal, scale_mode, st); }
+#endif
 
 }  // namespace qattn
