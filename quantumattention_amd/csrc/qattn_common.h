@@ -121,30 +121,58 @@ __device__ __attribute__((noinline)) int2 quant8_exact_call(const uint4 raw, flo
 template <int IN_FMT, int OUT_FMT>
 __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv) {
     if (IN_FMT != QATTN_FMT_BF16) return quant8_exact<IN_FMT, OUT_FMT>(raw, scale);
-    const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
-    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-    float q[8];
-    unsigned near = 0xffffu;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        q[2 * i] = __uint_as_float(w[i] << 16) * rinv;
-        q[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u) * rinv;
-        near = min(near, min((__float_as_uint(q[2 * i]) + 0x8004u) & 0xffffu, (__float_as_uint(q[2 * i + 1]) + 0x8004u) & 0xffffu));
-    }
-    const bool slow = near < 9u || !((__float_as_uint(scale) & 0x7f800000u) != 0x7f800000u);
-    if (__builtin_expect(slow, 0)) return quant8_exact_call<IN_FMT, OUT_FMT>(raw, scale);  // one out-of-line copy: rare
+    // Per pair of elements: unpack (2 VALU), v_pk_mul_f32, tie test on the packed low halves (v_perm, v_pk_add_u16,
+    // v_pk_min_u16), v_cvt_pk_bf16_f32, clamp of the packed bf16 magnitudes (and, v_pk_min_u16, and-or), and one
+    // v_cvt_scalef32_pk_{fp8,bf8}_bf16 at scale 1.0 -- bit-identical to unpack -> v_med3_f32 -> v_cvt_pk_fp8_f32 for every
+    // finite bf16 (tools/cvt_bf16_fp8_probe.hip) and 11 instead of 17 VALU per pair: the pre-pass is VALU-bound.
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    float c[8];
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    const unsigned qbits = OUT_FMT == QATTN_FMT_E4M3 ? 0x43e043e0u : 0x47604760u;   // bf16(448) / bf16(57344), both halves
+    const unsigned tie = 0x80048004u;
+    u16x2 pq, ptie, pnear = {0xffff, 0xffff};
+    __builtin_memcpy(&pq, &qbits, 4);
+    __builtin_memcpy(&ptie, &tie, 4);
+    b2 cl[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const b2 h = __builtin_convertvector(f2{q[2 * i], q[2 * i + 1]}, b2);  // v_cvt_pk_bf16_f32: RNE
+        const f2 q = f2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)} * rinv;
+        const unsigned lows = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x05040100u);   // the low halves of both quotients
+        u16x2 pl;
+        __builtin_memcpy(&pl, &lows, 4);
+        pnear = __builtin_elementwise_min(pnear, (u16x2)(pl + ptie));
+        const b2 h = __builtin_convertvector(q, b2);  // v_cvt_pk_bf16_f32: RNE
         unsigned u;
         __builtin_memcpy(&u, &h, 4);
-        c[2 * i] = __builtin_amdgcn_fmed3f(__uint_as_float(u << 16), -qmax, qmax);
-        c[2 * i + 1] = __builtin_amdgcn_fmed3f(__uint_as_float(u & 0xffff0000u), -qmax, qmax);
+        unsigned mag = u & 0x7fff7fffu;
+        u16x2 pm;
+        __builtin_memcpy(&pm, &mag, 4);
+        pm = __builtin_elementwise_min(pm, pq);
+        __builtin_memcpy(&mag, &pm, 4);
+        const unsigned c = mag | (u & 0x80008000u);
+        __builtin_memcpy(&cl[i], &c, 4);
     }
-    return make_int2(cvt4_fp8<OUT_FMT>(c[0], c[1], c[2], c[3]), cvt4_fp8<OUT_FMT>(c[4], c[5], c[6], c[7]));
+    const unsigned near = min((unsigned)pnear.x, (unsigned)pnear.y);
+    const bool slow = near < 9u || !((__float_as_uint(scale) & 0x7f800000u) != 0x7f800000u);
+    if (__builtin_expect(slow, 0)) return quant8_exact_call<IN_FMT, OUT_FMT>(raw, scale);  // one out-of-line copy: rare
+    s2 lo = {0, 0}, hi = {0, 0};
+    if (OUT_FMT == QATTN_FMT_E4M3) {
+        lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, cl[0], 1.0f, false);
+        lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, cl[1], 1.0f, true);
+        hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, cl[2], 1.0f, false);
+        hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, cl[3], 1.0f, true);
+    } else {
+        lo = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(lo, cl[0], 1.0f, false);
+        lo = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(lo, cl[1], 1.0f, true);
+        hi = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(hi, cl[2], 1.0f, false);
+        hi = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(hi, cl[3], 1.0f, true);
+    }
+    int2 r;
+    __builtin_memcpy(&r.x, &lo, 4);
+    __builtin_memcpy(&r.y, &hi, 4);
+    return r;
 }
 
 // q/k/v pre-pass launcher shared by qattn_quant_qkv_fp8 and the fused step entry (qattn_api.hip).  `ws` holds the amax bits

@@ -1,0 +1,53 @@
+// Development probe: does v_cvt_scalef32_pk_{fp8,bf8}_bf16 (scale 1.0) on magnitude-clamped packed bf16 give the same
+// bytes as unpack -> v_med3_f32 -> v_cvt_pk_{fp8,bf8}_f32 for every finite bf16 pattern?  (quant8's last three steps.)
+//   hipcc --offload-arch=gfx950 -O3 tools/cvt_bf16_fp8_probe.hip -o tools/bin/cvt_bf16_fp8_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+template <bool E5M2>
+__global__ void probe(unsigned* bad, unsigned* first) {
+    const unsigned lo = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. 65535: the low element; the high one is a rotation of it
+    const unsigned hi = (lo * 40503u + 12345u) & 0xffffu;
+    if ((lo & 0x7f80u) == 0x7f80u || (hi & 0x7f80u) == 0x7f80u) return;
+    const float qmax = E5M2 ? 57344.0f : 448.0f;
+    const unsigned qbits = E5M2 ? 0x47604760u : 0x43e043e0u;     // bf16(57344), bf16(448) in both halves
+    const unsigned u = lo | (hi << 16);
+    // A: the path in use
+    const float a0 = __builtin_amdgcn_fmed3f(__uint_as_float(u << 16), -qmax, qmax);
+    const float a1 = __builtin_amdgcn_fmed3f(__uint_as_float(u & 0xffff0000u), -qmax, qmax);
+    int ra = E5M2 ? __builtin_amdgcn_cvt_pk_bf8_f32(a0, a1, 0, false) : __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+    int ra_hi = E5M2 ? __builtin_amdgcn_cvt_pk_bf8_f32(a0, a1, 0x11110000, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0x11110000, true);
+    // B: clamp the magnitudes as packed u16, keep the signs, convert the pair directly
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    unsigned mag = u & 0x7fff7fffu;
+    u16x2 pm, pq;
+    __builtin_memcpy(&pm, &mag, 4); __builtin_memcpy(&pq, &qbits, 4);
+    pm = __builtin_elementwise_min(pm, pq);
+    __builtin_memcpy(&mag, &pm, 4);
+    const unsigned cl = mag | (u & 0x80008000u);
+    b2 h; __builtin_memcpy(&h, &cl, 4);
+    s2 z = {0, 0}, z2 = {0, 0x1111};
+    s2 rb = E5M2 ? __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(z, h, 1.0f, false) : __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(z, h, 1.0f, false);
+    s2 rb_hi = E5M2 ? __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(z2, h, 1.0f, true) : __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(z2, h, 1.0f, true);
+    unsigned b, bh; __builtin_memcpy(&b, &rb, 4); __builtin_memcpy(&bh, &rb_hi, 4);
+    if ((ra & 0xffff) != (b & 0xffff) || ((unsigned)ra_hi >> 16) != (bh >> 16)) {
+        if (atomicAdd(bad, 1u) == 0) { first[0] = u; first[1] = ra; first[2] = b; first[3] = ra_hi; first[4] = bh; }
+    }
+}
+
+int main() {
+    unsigned *bad, *first;
+    hipMalloc(&bad, 4); hipMalloc(&first, 32);
+    for (int f = 0; f < 2; f++) {
+        hipMemset(bad, 0, 4); hipMemset(first, 0, 32);
+        if (f) probe<true><<<256, 256>>>(bad, first); else probe<false><<<256, 256>>>(bad, first);
+        unsigned hb, hf[8];
+        hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost); hipMemcpy(hf, first, 32, hipMemcpyDeviceToHost);
+        printf("%s: %u mismatching pairs of 65536", f ? "e5m2" : "e4m3", hb);
+        if (hb) printf("  first: in %08x  f32-path %08x  bf16-path %08x  (hi-half %08x vs %08x)", hf[0], hf[1], hf[2], hf[3], hf[4]);
+        printf("\n");
+    }
+    return 0;
+}
