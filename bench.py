@@ -20,6 +20,10 @@ The JSON line also carries
   cpu_baseline -- the reference's CPU path (torch port of ops.py:64-95, oracle/torch_ref.py) timed on the host cores
                   on a bounded sample of the same workload;
   sustained_ms_per_step, c3_*, c5_* -- a >= 2 s back-to-back run and the causal / long-context configs (N=1 only).
+Timing protocol: --settle seconds (default 0.3) of untimed steps bring the idle GPU (sclk ~100 MHz) to its sustained,
+power-capped state (tools/time_ramp.py: the first 20 steps after idle run 16 % slower than the next thousands), then the W
+warm-up steps, a barrier + synchronize, EXACTLY K timed steps, a barrier + synchronize.  `settle_steps` reports how many
+steps the settle phase issued; `--settle 0` times the cold burst instead.
 """
 import argparse
 import json
@@ -49,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--precision", default="auto", choices=["auto", "fast", "accurate"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sustained run and the C3 / C5 configs")
+    ap.add_argument("--settle", type=float, default=0.3,
+                    help="seconds of untimed steps BEFORE the W warm-up steps (the idle GPU sits at ~100 MHz and needs ~40 ms of "
+                         "load to reach its sustained, power-capped state; 0 = time the cold burst)")
     ap.add_argument("--dry-run", action="store_true", help="host stub instead of the device step, gloo instead of RCCL")
     return ap.parse_args(argv)
 
@@ -168,7 +175,17 @@ def run_rank(args):
             dist.barrier()
         sync()
 
-    def timed(fn, warmup, steps):
+    settle_steps = 0
+
+    def timed(fn, warmup, steps, settle=0.0):
+        nonlocal settle_steps
+        if settle > 0:   # leave the idle power state first; reported as `settle_steps`, never part of the timed region
+            t_end = time.perf_counter() + settle
+            while time.perf_counter() < t_end:
+                for _ in range(10):
+                    fn()
+                sync()
+                settle_steps += 10
         for _ in range(warmup):
             fn()
         fence()
@@ -182,7 +199,7 @@ def run_rank(args):
         elapsed = timed(step, args.warmup, args.steps)
     else:
         with qa.config.patch(cfg):
-            elapsed = timed(step, args.warmup, args.steps)
+            elapsed = timed(step, args.warmup, args.steps, args.settle)
     ranks_seen = 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -197,6 +214,7 @@ def run_rank(args):
         "value": None, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": f"fp8_{args.fp8} (fp32 accumulate)", "data": "synthetic", "ranks_seen": ranks_seen,
+        "settle_steps": settle_steps,
         "config": {"workload": f"B={B} H={H} S={S} D={D} {'causal' if args.causal else 'non-causal'} fp8({args.fp8}) "
                                f"per GPU, bf16 in/out, head-wise scales, precision={args.precision} (BASELINE.json configs[1]"
                                f"{'; batch-sharded B=%d total, configs[3] at 8 GPUs' % (B * world) if world > 1 else ''})",
@@ -238,16 +256,15 @@ def run_rank(args):
             on its own launch stream (qattn_profile_attention) and returns their sum for the most recent step."""
             L.qattn_profile_attention(1)
             try:
-                for _ in range(3):
-                    fn()
-                tot = 0.0
-                for _ in range(n):
-                    fn()
-                    ms = L.qattn_last_attention_ms()   # waits for this step's attention launches
+                tot, reps = 0.0, 5
+                for _ in range(reps):
+                    for _ in range(max(n, 2)):   # back to back, no host wait in between: the last step runs in a full queue
+                        fn()
+                    ms = L.qattn_last_attention_ms()   # waits for the LAST step's attention launches
                     if ms < 0:
                         return None
                     tot += ms
-                return tot / n
+                return tot / reps
             finally:
                 L.qattn_profile_attention(0)
 
@@ -288,11 +305,19 @@ def run_rank(args):
         })
         if world == 1 and not args.no_extras:
             with qa.config.patch(cfg):
-                # sustained rate: >= 2 s of back-to-back steps, median of 20-step windows (power-limited kernels settle)
-                windows, t_end = [], time.perf_counter() + 2.0
-                while time.perf_counter() < t_end or len(windows) < 5:
-                    windows.append(timed(step, 0, 20) / 20 * 1e3)
-                windows.sort()
+                # sustained rate: >= 2 s of back-to-back steps, median of 20-step windows between HIP events (no host
+                # wait inside the run: the events are read after the last window)
+                evs, t_end = [torch.cuda.Event(enable_timing=True)], time.perf_counter() + 2.0
+                evs[0].record()
+                while time.perf_counter() < t_end or len(evs) < 6:
+                    for _ in range(20):
+                        step()
+                    evs.append(torch.cuda.Event(enable_timing=True))
+                    evs[-1].record()
+                    if len(evs) % 16 == 0:
+                        evs[-8].synchronize()   # bound the launch queue (the host runs ahead of the GPU)
+                torch.cuda.synchronize()
+                windows = sorted(a.elapsed_time(b) / 20 for a, b in zip(evs[:-1], evs[1:]))
                 line["sustained_ms_per_step"] = windows[len(windows) // 2]
                 line["sustained_windows"] = len(windows)
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
