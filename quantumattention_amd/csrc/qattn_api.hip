@@ -72,6 +72,8 @@ struct AttnCall {
     float sm_scale;
     int precision, lse_layout;
     unsigned* flags;   // nullptr or one word per (b, h, 32-row group) of THIS call
+    const float *ssq_q, *ssq_k;   // fused step, head-wise AUTO: the heads' partial sums of squares from the pre-pass (else nullptr)
+    int ssq_n;
     const void* q16;   // fused step (else nullptr): bf16 Q, quantised in the kernel from q_amax_bits; sq_out is written
     const unsigned* q_amax_bits;
     float* sq_out;
@@ -108,6 +110,11 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.precision = a.precision;
     p.two_term_keys = kTwoTermKeys;
     p.peak_r0 = a.precision == QATTN_PRECISION_AUTO ? kPeakR0 : 0.0f;
+    p.max_rescue = kMaxRescueWaves;
+    p.ssq_q = a.precision == QATTN_PRECISION_AUTO ? a.ssq_q : nullptr;   // (FAST: the caller vouches for flat rows)
+    p.ssq_k = p.ssq_q ? a.ssq_k : nullptr;
+    p.ssq_n = a.ssq_n; p.ssq_stride = kMomentSplits;
+    p.var_mul = sm * sm / ((float)a.Sq * (float)a.Skv * (float)a.D);
     p.flags = a.flags;
     p.lse_stride = (long)qattn_lse_row_stride(a.Sq, a.lse_layout);
     p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
@@ -118,6 +125,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.exact_exp = e.exact_exp;
     p.two_term_keys = e.two_term_keys;
     if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = e.peak_r0;
+    if (getenv("QATTN_MAX_RESCUE")) p.max_rescue = atoi(getenv("QATTN_MAX_RESCUE"));
     p.waves = !use_v2 ? kWaves : e.waves;
     p.nqb = ceil_div(a.Sq, p.waves * kQPerWave);
     p.lds_pad = e.lds; p.dbg = e.dbg; p.dbg_buf = nullptr;
@@ -269,7 +277,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
     if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
     AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
-               is_causal, sm_scale, precision, lse_layout, have_ws ? (unsigned*)workspace : nullptr, nullptr, nullptr, nullptr, 0};
+               is_causal, sm_scale, precision, lse_layout, have_ws ? (unsigned*)workspace : nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
     return attention_impl(a, (hipStream_t)stream, ds);
 }
@@ -301,12 +309,14 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     // them instead of sharing the CU, and the chip is power-limited on the attention kernel: the step got 19-31 % SLOWER.)
     unsigned* ws = (unsigned*)workspace;
     unsigned* flags = (unsigned*)((unsigned char*)workspace + (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16);
+    const bool moments = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
-                              numerics, ws, fuse_q, st);
+                              numerics, ws, fuse_q, moments, st);
     if (rc != QATTN_OK) return rc;
+    const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
     AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
                fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, flags,
-               fuse_q ? q : nullptr, fuse_q ? ws : nullptr, fuse_q ? scale_q : nullptr, numerics};
+               moments ? mom.part_q : nullptr, moments ? mom.part_k : nullptr, mom.nsplit, fuse_q ? q : nullptr, fuse_q ? ws : nullptr, fuse_q ? scale_q : nullptr, numerics};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

@@ -17,6 +17,27 @@ constexpr int kTwoTermKeys = 1024;           // query blocks that see fewer keys
 // One-term rows are re-done with two-term P when R = l / p_max (the inverse of the row's largest softmax weight) ends below
 // this: the error a single e4m3-rounded weight w contributes is about w * 2^-4 * |v - O|  
 constexpr float kPeakR0 = 24.0f;
+// Which blocks START in two-term mode: those whose rows are predicted to end below kPeakR0 anyway.  For scores ~ N(0, var)
+// over n keys the row sum is about n exp(var / 2) and the largest term sits about z standard deviations out, so the smallest
+// R in a block is about n exp(var / 2 - z sqrt(var)); z (AttnParams::peak_z = 1/2 + ln(kTwoTermKeys / kPeakR0) = 4.25) makes
+// that meet kPeakR0 at n = kTwoTermKeys for unit variance -- round 1's key-count rule is this rule at var = 1, which is what
+// a caller without the pre-pass's moments gets.  The fused step passes every head's sum of squares (ssq_q, ssq_k), and
+// var = sm_scale^2 sum_d E[q_d^2] E[k_d^2] ~= sm_scale^2 ssq_q ssq_k / (Sq Skv D): a head with score spread 2 goes
+// straight to two-term P instead of sweeping once in vain (AUTO on q x 2 data: 2.9x -> 1.9x the one-term time).  The
+// prediction only picks the starting mode; the R test after a one-term sweep stays the arbiter of accuracy.  Estimates
+// below kVarDeadband count as 1: unit-variance data takes the same decisions with and without the moments, so the fused step
+// and the quantise-then-attend sequence of C calls stay bit-identical there.
+constexpr float kVarDeadband = 1.5f;
+__device__ inline float predicted_r(float nkeys, float var, float z) { return nkeys * __expf(0.5f * var - z * sqrtf(var)); }
+// a head's sum of squares from its partial sums, the same value in every lane of every wave (fixed order: lane l adds
+// l, l + 64, ...; then the xor tree)
+__device__ inline float sum_partials(const float* part, int n, int lane) {
+    float t = 0.0f;
+    for (int i = lane; i < n; i += 64) t += part[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    return t;
+}
 
 struct AttnParams {
     const unsigned char* q;
@@ -38,7 +59,13 @@ struct AttnParams {
     int precision;   // QATTN_PRECISION_*
     int two_term_keys;  // kTwoTermKeys (a development switch can change it)
     int n_two;       // leading query blocks per head that start in two-term mode (set by the launcher)
-    float peak_r0;   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
+    float peak_r0;
+    const float* ssq_q;          // fused step, head-wise: partial sums of squares of every q head [B*Hq][ssq_stride] and k
+    const float* ssq_k;          //   head [B*Hkv][ssq_stride], ssq_n of them valid per head (else nullptr)
+    int ssq_n, ssq_stride;
+    float peak_z;                // see predicted_r
+    float var_mul;               // score variance of head (bh, kvh) ~= sum(ssq_q[bh]) * sum(ssq_k[kvh]) * var_mul
+    int max_rescue;              // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
     unsigned* flags; // templated kernel (qattn_attn_v4.hip): one word per (head, 32-row group), set by the one-term launch
     long lse_stride; // floats between the LSE rows of consecutive (b, h)
     float lse_mul;   // 1 (natural log-sum-exp) or -sqrt(D) (QATTN_LSE_REFERENCE)

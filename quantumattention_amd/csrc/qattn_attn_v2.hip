@@ -597,7 +597,7 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
         for (int w = 0; w < NW; w++) flagged |= (vote[w] != 0u ? 1u : 0u) << w;
         flagged = __builtin_amdgcn_readfirstlane(flagged);
         const int nf = __builtin_popcount(flagged);
-        if (nf > kMaxRescueWaves) return true;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
+        if (nf > p.max_rescue) return true;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
         if constexpr (!TOKEN && NW == 8) {
             for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
                 // the rescued wave's Q^T fragments are still parked in its LDS slots; the K/V ring is idle and holds the merge
@@ -720,16 +720,26 @@ __device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* s
 // Q16: the fused step (qattn_fp8_quant_attention_forward): Q arrives as bf16 and is quantised here, row by row, with the
 // same quant8 sequence as the pre-pass (bit-identical q8), from the head's abs-max bits -- the pre-pass then neither
 // re-reads Q nor writes q8, and this kernel reads 2 instead of 1 byte per Q element once.
-// One launch covers every query block of every head: blocks qb < p.n_two go straight to the two-term pass.
+// One launch covers every query block of every head; a block whose rows are predicted peaked (predicted_r) starts two-term.
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int head, qb;
     map_block(p, blockIdx.x, p.nqb, CAUSAL, head, qb);
-    // One copy of each pass: a peaked block loops back into the two-term code that the blocks qb < n_two enter directly.
+    // One copy of each pass: a peaked block loops back into the two-term code that the predicted-peaked blocks enter directly.
     // Every per-lane value is re-derived inside block_pass from an opaque copy of the thread index, so nothing of the
     // one-term pass stays live in registers across the two-term loop (and vice versa).
-    bool two = qb < p.n_two;  // workgroup-uniform
+    bool two = p.n_two != 0;  // workgroup-uniform; n_two = nqb: every block (QATTN_PRECISION_ACCURATE)
+    if (!two) {
+        float var = 1.0f;
+        if (p.ssq_q) {
+            const int lane = threadIdx.x & 63, kvh = (head / p.Hq) * p.Hkv + (head % p.Hq) / (p.Hq / p.Hkv);
+            var = sum_partials(p.ssq_q + (long)head * p.ssq_stride, p.ssq_n, lane) * sum_partials(p.ssq_k + (long)kvh * p.ssq_stride, p.ssq_n, lane) * p.var_mul;
+            if (!(var >= kVarDeadband)) var = 1.0f;
+        }
+        const int nkeys = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;   // keys the block's first row attends
+        two = __builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, p.peak_z) < kPeakR0 ? 1 : 0) != 0;   // (every lane holds the same value)
+    }
     int tid = threadIdx.x;
 #ifdef QATTN_DEV
     const unsigned long long dbg_entry = (p.dbg & 16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -772,11 +782,10 @@ static int launch_attn_v2_one(const AttnParams& p, hipStream_t st) {
 template <int D, int NW, int FMT, bool CAUSAL>
 static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t st) {
     AttnParams p = pin;
-    // leading query blocks that run two-term P from the start: every block (QATTN_PRECISION_ACCURATE), or the blocks whose
-    // first row sees fewer than kTwoTermKeys keys -- there even a flat row averages over too few keys
-    if (p.precision == QATTN_PRECISION_ACCURATE) p.n_two = p.nqb;
-    else if (CAUSAL) p.n_two = min(p.nqb, ceil_div(min(p.two_term_keys, p.Skv), NW * kQPerWave));
-    else p.n_two = p.Skv < p.two_term_keys ? p.nqb : 0;
+    // blocks that run two-term P from the start: every block (QATTN_PRECISION_ACCURATE), else the kernel's predicted_r rule
+    // (at unit score variance: the blocks whose first row sees fewer than kTwoTermKeys keys)
+    p.n_two = p.precision == QATTN_PRECISION_ACCURATE ? p.nqb : 0;
+    p.peak_z = (float)p.two_term_keys > kPeakR0 ? 0.5f + logf((float)p.two_term_keys / kPeakR0) : 0.0f;
 #ifdef QATTN_DEV
     if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])

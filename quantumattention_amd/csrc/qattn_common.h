@@ -178,8 +178,23 @@ __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv
 // q/k/v pre-pass launcher shared by qattn_quant_qkv_fp8 and the fused step entry (qattn_api.hip).  `ws` holds the amax bits
 // of q [B*Hq], k [B*Hkv], v [B*Hkv] (zeroed here).  skip_q_payload: q8 / scale_q are not written (the attention kernel
 // quantises its own Q rows from the 16-bit tensor and the q amax bits).
+// want_moments (head-wise only): the abs-max pass also leaves the sums of squares of every q and k head in the workspace, as
+// `nsplit` partial sums per head (stride kMomentSplits), where quant_moments() finds them (the attention kernel's score-spread
+// estimate, qattn_attn.h predicted_r).
+constexpr int kMomentSplits = 256;   // >= the abs-max pass's blocks per head
+struct QuantMoments { const float* part_q; const float* part_k; int nsplit; };
+inline int amax_splits(int Sq, int Skv, int D) {
+    const long vecs = (long)(Sq > Skv ? Sq : Skv) * D / 8;
+    const long s = (vecs + 2047) / 2048;   // 8 x 16 B per thread and block
+    return s < 1 ? 1 : s > kMomentSplits ? kMomentSplits : (int)s;
+}
+inline QuantMoments quant_moments(const unsigned* ws, int B, int Hq, int Hkv, int Sq, int Skv, int D) {
+    const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
+    const float* s = reinterpret_cast<const float*>(ws + nq + 2 * nk);
+    return QuantMoments{s, s + nq * kMomentSplits, amax_splits(Sq, Skv, D)};
+}
 int launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                      float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt, int scale_mode,
-                     int numerics, unsigned* ws, bool skip_q_payload, hipStream_t st);
+                     int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, hipStream_t st);
 
 }  // namespace qattn

@@ -201,6 +201,11 @@ struct QuantJob {
     float* scale;         // [G] (head) or [G, S] (token)
     unsigned* amax_bits;  // [G] workspace (head-wise)
     int G, S, layout, token;
+    // head-wise q and k of the fused step (else nullptr): every block of the abs-max pass leaves the sum of squares of its
+    // share of the head in part[g][block]; the attention kernel adds a head's partial sums in a fixed order (deterministic, no
+    // atomics, and no device-scope fence -- those write back a whole L2 on this chip: a last-block-reduces variant took
+    // 517 us instead of 78) for its score-spread estimate (qattn_attn.h: predicted_r).
+    float* part;          // [G][kMomentSplits]
 };
 struct QuantJobs {
     QuantJob j[3];
@@ -218,7 +223,10 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
     long end = beg + per;
     if (end > vecs_per_group) end = vecs_per_group;
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
     unsigned m0 = 0, m1 = 0;
+    f2 ss = {0.0f, 0.0f};
+    const bool moments = jb.part != nullptr;   // (uniform per blockIdx.z)
     auto fold = [&](const uint4& v) {
         unsigned a = v.x & 0x7fff7fffu, b = v.y & 0x7fff7fffu, c = v.z & 0x7fff7fffu, d = v.w & 0x7fff7fffu;
         u16x2 pa, pb, pc, pd, p0, p1;
@@ -227,6 +235,15 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
         p0 = __builtin_elementwise_max(p0, __builtin_elementwise_max(pa, pb));
         p1 = __builtin_elementwise_max(p1, __builtin_elementwise_max(pc, pd));
         __builtin_memcpy(&m0, &p0, 4); __builtin_memcpy(&m1, &p1, 4);
+        if (moments) {
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const f2 x = IN_FMT == QATTN_FMT_BF16 ? f2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)}
+                                                      : f2{load16f<IN_FMT>((unsigned short)(w[i] & 0xffffu)), load16f<IN_FMT>((unsigned short)(w[i] >> 16))};
+                ss = __builtin_elementwise_fma(x, x, ss);
+            }
+        }
     };
     // 8 independent 16-byte loads in flight per thread (a plain strided loop kept ~2 and ran at 4.8 TB/s)
     long i = beg + threadIdx.x;
@@ -242,11 +259,18 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
     __shared__ unsigned red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __shared__ float red_ss[4];
+    float s1 = ss.x + ss.y;
+    if (moments) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; red_ss[threadIdx.x >> 6] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(red[0], red[1]), max(red[2], red[3]));
         atomicMax(jb.amax_bits + g, __float_as_uint(load16f<IN_FMT>((unsigned short)m)));
+        if (moments) jb.part[g * kMomentSplits + blockIdx.x] = (red_ss[0] + red_ss[1]) + (red_ss[2] + red_ss[3]);
     }
 }
 
@@ -738,7 +762,9 @@ extern "C" int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, i
 
 extern "C" size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0) return 0;
-    return (size_t)B * (Hq + 2 * (size_t)Hkv) * sizeof(unsigned);
+    // [abs-max bits of q, k, v (zeroed every call) | partial sums of squares of q, k: kMomentSplits per head]
+    const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
+    return ((nq + 2 * nk) + qattn::kMomentSplits * (nq + nk)) * sizeof(unsigned);
 }
 
 #ifdef QATTN_DEV
@@ -789,18 +815,23 @@ extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, 
     const size_t need = qattn_quant_qkv_workspace_bytes(B, Hq, Hkv);
     if (!workspace || workspace_bytes < need) return QATTN_ERR_WORKSPACE;
     return qattn::launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, out_fmt, scale_mode,
-                                   numerics, (unsigned*)workspace, false, (hipStream_t)stream);
+                                   numerics, (unsigned*)workspace, false, false, (hipStream_t)stream);
 }
 
 int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                             float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt,
-                            int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, hipStream_t st) {
+                            int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, hipStream_t st) {
     const int tok = scale_mode == QATTN_SCALE_TOKEN;
-    if (hipMemsetAsync(ws, 0, qattn_quant_qkv_workspace_bytes(B, Hq, Hkv), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+    const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
+    if (hipMemsetAsync(ws, 0, (nq + 2 * nk) * sizeof(unsigned), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+    float* part = reinterpret_cast<float*>(ws + nq + 2 * nk);   // q heads then k heads
+    const bool moments = !tok && want_moments;
     QuantJobs jobs;
-    jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok};
-    jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + (size_t)B * Hq, B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok};
-    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + (size_t)B * (Hq + Hkv), B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0};
+    jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok,
+                         moments ? part : nullptr};
+    jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + nq, B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
+                         moments ? part + nq * kMomentSplits : nullptr};
+    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + nq + nk, B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0, nullptr};
     // (Tried and dropped: one tensor at a time -- amax then quantise, hoping the re-read hits the 256 MiB Infinity Cache --
     // was 13 % slower than the two fused launches; a one-pass register-resident variant with a cross-workgroup amax
     // exchange was 2-6x slower, the agent-scope atomics + spinning cost more than the second read.  A third variant --
@@ -812,10 +843,7 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
     // gains 2 % and the step loses 1 % -- the attention kernel finds the fresh fp8 K and V in the Infinity Cache.)
     const int Gmax = B * (Hq > Hkv ? Hq : Hkv), Smax = Sq > Skv ? Sq : Skv;
     {
-        const long vecs = (long)Smax * D / 8;
-        int splits = (int)((vecs + 2047) / 2048);  // 8 x 16 B per thread and block
-        if (splits < 1) splits = 1;
-        if (splits > 256) splits = 256;
+        const int splits = amax_splits(Sq, Skv, D);
 #ifdef QATTN_DEV
         // (experiment: the one-read team kernel for head-wise K and V; one workgroup per CU, whole teams per XCD)
         const int NS = (Skv + kSliceBytes / (D * 2) - 1) / (kSliceBytes / (D * 2));

@@ -98,6 +98,23 @@ def test_flat_rows_keep_the_one_term_result_bit_for_bit():
     assert err_stats(f[:1, :2], ref)[0] < TOL      # the unchecked one-term path is accurate on flat rows
 
 
+def test_heads_with_wide_scores_start_in_two_term_mode():
+    """The fused step hands the attention kernel every head's sum of squares (abs-max pass, deterministic partial sums); a head
+    whose predicted score variance is clearly above 1 starts its blocks in two-term mode instead of sweeping once in vain
+    (qattn_attn.h predicted_r).  Observable without a clock: for such a head AUTO must return ACCURATE's bits, for a
+    unit-variance head (below the dead band) it must not -- there the one-term result stands."""
+    torch.manual_seed(5)
+    S, D = 2048, 128
+    q, k, v = (torch.randn(1, 2, S, D) for _ in range(3))
+    q[:, 1] *= 2.0                                            # head 0: score std 1, head 1: score std 2
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    auto, acc = _run(q, k, v, False, "auto"), _run(q, k, v, False, "accurate")
+    np.testing.assert_array_equal(auto[0, 1], acc[0, 1])
+    assert not np.array_equal(auto[0, 0], acc[0, 0])
+    ref = _oracle(q, k, v, False)
+    assert err_stats(auto, ref)[0] < TOL
+
+
 def test_lse_reference_layout_and_convention():
     """the reference-defined (disabled) vector, tk/attention.py:333-346 / :439-446:
     L = -(ln l + m ln2) sqrt(D), rows of consecutive (b, h) ld = ceil(Sq*4/16)*16/4 floats apart."""
