@@ -126,7 +126,9 @@ int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale, int B, in
 /*
  * Fused pre-pass of one attention call: quantises q, k and v in ONE amax launch + ONE quantise launch
  * (q8 row-major, k8 QATTN_LAYOUT_KFRAG, v8 QATTN_LAYOUT_VFRAG; q and k scaled per `scale_mode`, v always head-wise).
- * Same numerics as three qattn_quant_fp8 calls.  `workspace` needs qattn_quant_qkv_workspace_bytes() bytes.
+ * Same numerics as three qattn_quant_fp8 calls.  `workspace` needs qattn_quant_qkv_workspace_bytes() bytes (one abs-max word
+ * per head of q, k, v + 256 partial sums of squares per head of q and k, which the fused entry below fills for its
+ * attention kernel; about 1 KiB per head).
  * This is what `_fp8_attention_wrapper` does for its two tensors at nn.py:410-418, plus the build's quantised V.
  */
 size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv);
@@ -168,7 +170,10 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
  * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
- * and one write of Q.  Results are bit-identical to the separate calls.
+ * and one write of Q.  Results are bit-identical to the separate calls, with one documented exception: under
+ * QATTN_PRECISION_AUTO (head-wise, D = 128) the pre-pass also hands the attention kernel every head's sum of squares, and a
+ * head whose predicted score variance is >= 1.5 starts in two-term mode (what QATTN_PRECISION_ACCURATE computes for it) instead
+ * of being swept once with one-term P first; heads below that -- N(0,1)-like data -- take the same decisions as the separate calls.
  */
 size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int Hkv, int Sq);
 int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8, void* k8,
