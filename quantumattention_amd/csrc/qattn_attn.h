@@ -65,6 +65,8 @@ struct AttnParams {
     int ssq_n, ssq_stride;
     float peak_z;                // see predicted_r
     float var_mul;               // score variance of head (bh, kvh) ~= sum(ssq_q[bh]) * sum(ssq_k[kvh]) * var_mul
+    int total_blocks;            // B * Hq * nqb (set by the launcher); the grid may be smaller: workgroups walk blocks bid, bid + gridDim.x, ...
+    int persistent;              // one workgroup per CU instead of one per block
     int max_rescue;              // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
     unsigned* flags; // templated kernel (qattn_attn_v4.hip): one word per (head, 32-row group), set by the one-term launch
     long lse_stride; // floats between the LSE rows of consecutive (b, h)

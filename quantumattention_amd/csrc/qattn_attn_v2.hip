@@ -540,7 +540,7 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
-            const long wid = (long)blockIdx.x * NW + wave;
+            const long wid = (bh * p.nqb + (q0 - wave * kQPerWave) / (NW * kQPerWave)) * NW + wave;
             p.dbg_buf[2 * wid] = t1 - dbg_t0;
             p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
             p.dbg_buf[(1 << 18) + 4 * wid + 1] = dbg_r0;   // timeline: sweep start / end (100 MHz ticks)
@@ -630,7 +630,7 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
 // Everything a wave derives from its thread / block index for one pass over its query rows, and that pass itself (the Q^T
 // fragments are re-loaded by a second pass: a few KiB against the pass's megabytes of K / V).
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16>
-__device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* smem, int tid, bool check_peaked) {
+__device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
     constexpr int KS = D / 64;      // QK^T k-steps
@@ -639,7 +639,7 @@ __device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* s
     const int ql = lane & 31, hh = lane >> 5;
 
     int head, qb;
-    map_block(p, blockIdx.x, p.nqb, CAUSAL, head, qb);
+    map_block(p, bid, p.nqb, CAUSAL, head, qb);
     const int b = head / p.Hq, h = head % p.Hq;
     const int hkv = h / (p.Hq / p.Hkv);
     const long bh = (long)b * p.Hq + h;
@@ -715,20 +715,14 @@ __device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* s
         p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q);
 }
 
-// QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
-// BYTE: the one-term pass uses the byte exponential (else exact v_exp_f32 + RNE conversion, needed for the LSE output).
-// Q16: the fused step (qattn_fp8_quant_attention_forward): Q arrives as bf16 and is quantised here, row by row, with the
-// same quant8 sequence as the pre-pass (bit-identical q8), from the head's abs-max bits -- the pre-pass then neither
-// re-reads Q nor writes q8, and this kernel reads 2 instead of 1 byte per Q element once.
-// One launch covers every query block of every head; a block whose rows are predicted peaked (predicted_r) starts two-term.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One 256-row block: a block whose rows are predicted peaked (predicted_r) starts two-term; a one-term pass that finds too
+// many peaked rows loops back into the same two-term code.
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16>
+__device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* smem, int bid) {
     int head, qb;
-    map_block(p, blockIdx.x, p.nqb, CAUSAL, head, qb);
-    // One copy of each pass: a peaked block loops back into the two-term code that the predicted-peaked blocks enter directly.
-    // Every per-lane value is re-derived inside block_pass from an opaque copy of the thread index, so nothing of the
-    // one-term pass stays live in registers across the two-term loop (and vice versa).
+    map_block(p, bid, p.nqb, CAUSAL, head, qb);
+    // One copy of each pass.  Every per-lane value is re-derived inside block_pass from an opaque copy of the thread index, so
+    // nothing of the one-term pass stays live in registers across the two-term loop (and vice versa).
     bool two = p.n_two != 0;  // workgroup-uniform; n_two = nqb: every block (QATTN_PRECISION_ACCURATE)
     if (!two) {
         float var = 1.0f;
@@ -746,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     auto dbg_exit = [&]() {
         if ((p.dbg & 16) && (threadIdx.x & 63) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row stores have left
-            const long wid = (long)blockIdx.x * NW + (threadIdx.x >> 6);
+            const long wid = ((long)head * p.nqb + qb) * NW + (threadIdx.x >> 6);
             p.dbg_buf[(1 << 18) + 4 * wid + 0] = dbg_entry;
             p.dbg_buf[(1 << 18) + 4 * wid + 3] = __builtin_amdgcn_s_memrealtime();
         }
@@ -757,18 +751,69 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     for (;;) {
         asm volatile("" : "+v"(tid));
         if (two) {
-            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, false);
-            dbg_exit();
-            return;
+            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, bid, false);
+            break;
         }
-        if (!block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, p.peak_r0 > 0.0f)) { dbg_exit(); return; }
+        if (!block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, bid, p.peak_r0 > 0.0f)) break;
         two = true;  // a row of this block is peaked: every wave is past the vote barrier, hence done with the K/V ring
+    }
+    dbg_exit();
+}
+
+// QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
+// BYTE: the one-term pass uses the byte exponential (else exact v_exp_f32 + RNE conversion, needed for the LSE output).
+// Q16: the fused step (qattn_fp8_quant_attention_forward): Q arrives as bf16 and is quantised here, row by row, with the
+// same quant8 sequence as the pre-pass (bit-identical q8), from the head's abs-max bits -- the pre-pass then neither
+// re-reads Q nor writes q8, and this kernel reads 2 instead of 1 byte per Q element once.
+// One launch covers every query block of every head.  Non-causal launches are PERSISTENT: one workgroup per CU (LDS allows
+// no more) walks the blocks blockIdx.x, + gridDim.x, ... -- the same blocks the hardware would have handed that XCD one by
+// one (bid & 7 is preserved) -- without a workgroup launch, LDS allocation and wave start between them (-1.6 % fast,
+// -2.5 % auto at C2).  Causal launches keep one workgroup per block: their blocks differ in length, the hardware's
+// hand-out balances them, a static stride does not (+6 %).
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p_arg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (CAUSAL) {
+        run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16>(p_arg, smem, blockIdx.x);
+    } else {
+        const int nblocks = p_arg.total_blocks;
+        for (int bid = blockIdx.x; bid < nblocks; bid += gridDim.x) {
+            // the parameters are re-read from the kernel-argument segment every block (scalar loads): left to the compiler they
+            // are hoisted out of this loop, stay live across whole blocks and push the scalar file into spilling
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef const __attribute__((address_space(4))) AttnParams* KernargPtr;
+            KernargPtr pk = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();   // AttnParams is the kernel's only argument
+            asm volatile("" : "+s"(pk));
+            const AttnParams& p = *(const AttnParams*)pk;
+#else
+            const AttnParams& p = p_arg;
+#endif
+            run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16>(p, smem, bid);
+            if (bid + (int)gridDim.x < nblocks) __syncthreads();   // every wave has left the ring and the Q slots before the next block fills them
+        }
     }
 }
 
+// CUs of the current device (cached per device ordinal)
+static int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cached[dev] = n > 0 ? n : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+
 template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16 = false>
-static int launch_attn_v2_one(const AttnParams& p, hipStream_t st) {
-    const int grid = p.B * p.Hq * p.nqb;
+static int launch_attn_v2_one(const AttnParams& pin, hipStream_t st) {
+    AttnParams p = pin;
+    p.total_blocks = p.B * p.Hq * p.nqb;
+    // one persistent workgroup per CU (a multiple of 8 keeps every workgroup's blocks on one XCD); fewer blocks than CUs: one each
+    const int cus = cu_count() & ~7;
+    const int grid = (!CAUSAL && p.persistent && cus >= 8 && p.total_blocks > cus) ? cus : p.total_blocks;
     size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64;  // K/V ring + parked Q^T fragments + per-wave vote words
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
@@ -791,7 +836,7 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
         const int grid = p.B * p.Hq * p.nqb;
         const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64;
-        p.n_two = 0; p.peak_r0 = 0.0f;
+        p.n_two = 0; p.peak_r0 = 0.0f; p.total_blocks = grid;
 #define QATTN_ABL_CASE(M)                                                                                          \
         case M: {                                                                                                  \
             auto kern = attn_fwd_kernel_v2<D, 8, QATTN_FMT_E4M3, QATTN_FMT_E4M3, false, false, true, M>;           \
