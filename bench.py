@@ -284,6 +284,8 @@ def run_rank(args):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     step()
+                for _ in range(30):   # the first replays of a fresh graph are slow (instantiation, upload)
+                    g.replay()
                 graph_ms = event_time(g.replay, args.steps)
             except Exception as exc:
                 print(f"[bench] HIP graph capture skipped: {exc}", file=sys.stderr)
