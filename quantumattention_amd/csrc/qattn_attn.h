@@ -229,13 +229,14 @@ __device__ __forceinline__ v8i gload_frag(const unsigned char* base) {
 template <int D>
 constexpr int rescue_slot_bytes() { return ((D / 32) * 16 + 2) * 64 * 4; }   // one wave's partial {O^T, m, l}
 
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, typename QFrag>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QLDS = false, typename QFrag>
 __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                             int r0, int wave, int lane, long bh, long kv_head, float c, const float* skt, QFrag&& qfrag) {
     static_assert(NW == 8, "three merge rounds");
     constexpr int CH = 64 * D, KS = D / 64, MB = D / 32;
     constexpr int SLOT = rescue_slot_bytes<D>();
-    constexpr bool QPRE = D <= 128;   // Q^T fragments held in registers (D = 256: re-fetched per chunk, registers go to O^T)
+    constexpr bool QPRE = D <= 128 && !QLDS;   // Q^T fragments held in registers (D = 256: re-fetched per chunk, registers go to
+                                               // O^T; QLDS: the caller's qfrag reads LDS, cheap enough to repeat per chunk)
     constexpr int VB = MB > 4 ? 2 : MB;   // V fragments requested ahead of the PV MFMAs
     const int ql = lane & 31, hh = lane >> 5;
     const int row = r0 + ql;
@@ -254,19 +255,35 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
 #pragma unroll
         for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
     float m_run = -1.0e30f, l_run = 0.0f;
+    // The wave's next K chunk travels by LDS-DMA into its own CH bytes of `smem` (the merge slots alias them later) while the
+    // current chunk is exponentiated: a chunk then waits for one L2 round trip (its V fragments, under the softmax) instead of
+    // two in a row (K before the first MFMA); in registers the same prefetch spilled.
+    static_assert(NW * CH <= 4 * SLOT, "the K prefetch areas fit the merge slots' LDS");
+    unsigned char* kpre = smem + wave * CH;
+    auto dma_k = [&](int t) {
+        const unsigned char* src = kg + (long)t * CH + (lane << 4);
+#pragma unroll
+        for (int i = 0; i < CH / 1024; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                             (__attribute__((address_space(3))) void*)(kpre + i * 1024), 16, 0, 0);
+    };
+    if (t0 < t1) dma_k(t0);
     for (int t = t0; t < t1; t++) {
-        const unsigned char* kc = kg + (long)t * CH + frag_lane_off;
+        const unsigned char* kc = kpre + frag_lane_off;
         const unsigned char* vc = vg + (long)t * CH + frag_lane_off;
         v16f s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t) is in LDS
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-            const v8i ka = gload_frag(kc + ((0 * KS + s) << 11)), kb = gload_frag(kc + ((1 * KS + s) << 11));
+            const v8i ka = lds_read_frag(kc + ((0 * KS + s) << 11)), kb = lds_read_frag(kc + ((1 * KS + s) << 11));
             const v8i qs = QPRE ? qf[QPRE ? s : 0] : qfrag(s);
             s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qs, s0);
             s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qs, s1);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and in registers: the area can take K(t + 1)
+        if (t + 1 < t1) dma_k(t + 1);
         v8i vf[VB];
 #pragma unroll
         for (int m = 0; m < VB; m++) vf[m] = gload_frag(vc + (m << 11));   // in flight under the softmax
@@ -324,6 +341,7 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
         }
     }
     // ---- merge the NW partials pairwise through LDS: {4..7} -> {0..3}, {2,3} -> {0,1}, {1} -> {0}
+    __syncthreads();   // every wave is done with its K prefetch area, which the slots alias
     float* slots = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int half = NW / 2; half >= 1; half >>= 1) {

@@ -503,11 +503,13 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
 }
 
 // One pass of a wave over its KV range with P in TWO (hi + lo) or one term, BYTE-exponential or exact, followed by the
-// row sums.  Returns true when `check_peaked` is set and some row of the WORKGROUP turned out to be peaked (its largest
-// softmax weight 1 / R exceeds 1 / peak_r0): nothing has been stored then and the caller repeats the block in two-term
-// mode.  Otherwise the wave's 32 output rows (and the optional LSE) are stored.
+// row sums.  With `check_peaked`, rows of the WORKGROUP that turned out peaked (largest softmax weight 1 / R above
+// 1 / peak_r0) make it return, workgroup-uniform: kPassRedo -- too many, nothing of the flagged waves is stored, the
+// caller repeats the block in two-term mode -- or the bit mask of the (at most max_rescue) waves whose 32-row groups
+// rescue_pass then recomputes; the other waves' rows (and the optional LSE) are stored.  0: everything is stored.
+constexpr int kPassRedo = 1 << 30;
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, typename LoadQ>
-__device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
+__device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
                                              int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q) {
     constexpr int MB = D / 32;
@@ -597,19 +599,9 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
         for (int w = 0; w < NW; w++) flagged |= (vote[w] != 0u ? 1u : 0u) << w;
         flagged = __builtin_amdgcn_readfirstlane(flagged);
         const int nf = __builtin_popcount(flagged);
-        if (nf > p.max_rescue) return true;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
-        if constexpr (!TOKEN && NW == 8) {
-            for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
-                // the rescued wave's Q^T fragments are still parked in its LDS slots; the K/V ring is idle and holds the merge
-                const int fw = __builtin_ctz(rest);
-                const unsigned char* qsrc = smem + kStagesV2 * 2 * 64 * D + fw * ((D / 64) << 11) + ((lane >> 5) << 10) + ((lane & 31) << 4);
-                rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL, false>(p, smem, kg, vg, q0 - wave * kQPerWave + fw * kQPerWave, wave, lane, bh, kv_head, c,
-                                                                nullptr, [&](int s_) { return lds_read_frag(qsrc + (s_ << 11)); });
-            }
-        } else {
-            if (nf > 0) return true;
-        }
-        return false;
+        if (nf > p.max_rescue) return kPassRedo;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
+        if constexpr (!TOKEN && NW == 8) return (int)flagged;   // 0: done; else the waves whose 32-row groups rescue_pass recomputes
+        return nf > 0 ? kPassRedo : 0;
     }
 
     // ---- normalise, convert, store
@@ -624,13 +616,13 @@ __device__ __forceinline__ bool attend_block(const AttnParams& p, unsigned char*
             p.lse[bh * p.lse_stride + qrow] = lse * p.lse_mul;
         }
     }
-    return false;
+    return 0;
 }
 
 // Everything a wave derives from its thread / block index for one pass over its query rows, and that pass itself (the Q^T
 // fragments are re-loaded by a second pass: a few KiB against the pass's megabytes of K / V).
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16>
-__device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked) {
+__device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
     constexpr int KS = D / 64;      // QK^T k-steps
@@ -715,6 +707,36 @@ __device__ __forceinline__ bool block_pass(const AttnParams& p, unsigned char* s
         p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q);
 }
 
+// The rescue of a block's flagged 32-row groups as a pass of its own: everything is derived afresh from the (opaque)
+// thread index and the block id, so that nothing of the sweep is live here and nothing of this is live in the sweep.  The
+// rescued wave's Q^T fragments are still parked in its LDS slots; the K/V ring is idle and holds the prefetch and the merge.
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool Q16>
+__device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, unsigned flagged) {
+    constexpr int CH = 64 * D;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int head, qb;
+    map_block(p, bid, p.nqb, CAUSAL, head, qb);
+    const int b = head / p.Hq, h = head % p.Hq;
+    const long bh = (long)b * p.Hq + h;
+    const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+    const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
+    const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
+    float c;
+    if (Q16) {
+        const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
+        c = p.sm_log2e * make_scale(__uint_as_float(p.q_amax_bits[bh]), inv_qmax, p.q_numerics, QATTN_FMT_BF16) * p.sk[kv_head];
+    } else {
+        c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
+    }
+    for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
+        const int fw = __builtin_ctz(rest);
+        const unsigned char* qsrc = smem + kStagesV2 * 2 * 64 * D + fw * ((D / 64) << 11) + ((lane >> 5) << 10) + ((lane & 31) << 4);
+        rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL, false, true>(p, smem, kg, vg, qb * (NW * kQPerWave) + fw * kQPerWave, wave, lane, bh, kv_head, c,
+                                                               nullptr, [&](int s_) { return lds_read_frag(qsrc + (s_ << 11)); });
+    }
+}
+
 // One 256-row block: a block whose rows are predicted peaked (predicted_r) starts two-term; a one-term pass that finds too
 // many peaked rows loops back into the same two-term code.
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16>
@@ -754,8 +776,16 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
             block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, bid, false);
             break;
         }
-        if (!block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, bid, p.peak_r0 > 0.0f)) break;
-        two = true;  // a row of this block is peaked: every wave is past the vote barrier, hence done with the K/V ring
+        const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, bid, p.peak_r0 > 0.0f);
+        if (r == 0) break;
+        if (r != kPassRedo) {   // a few peaked groups (every wave is past the vote barrier, hence done with the K/V ring)
+            if constexpr (!TOKEN && NW == 8) {
+                asm volatile("" : "+v"(tid));
+                rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16>(p, smem, tid, bid, (unsigned)r);
+            }
+            break;
+        }
+        two = true;  // many rows of this block are peaked: the block repeats in two-term mode
     }
     dbg_exit();
 }
