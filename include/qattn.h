@@ -126,9 +126,9 @@ int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale, int B, in
 /*
  * Fused pre-pass of one attention call: quantises q, k and v in ONE amax launch + ONE quantise launch
  * (q8 row-major, k8 QATTN_LAYOUT_KFRAG, v8 QATTN_LAYOUT_VFRAG; q and k scaled per `scale_mode`, v always head-wise).
- * Same numerics as three qattn_quant_fp8 calls.  `workspace` needs qattn_quant_qkv_workspace_bytes() bytes (one abs-max word
- * per head of q, k, v + 256 partial sums of squares per head of q and k, which the fused entry below fills for its
- * attention kernel; about 1 KiB per head).
+ * Same numerics as three qattn_quant_fp8 calls.  `workspace` needs qattn_quant_qkv_workspace_bytes() bytes (256 per-block
+ * abs-max words per head of q, k, v + 256 per-block sums of squares per head of q and k, which the fused entry below fills
+ * for its attention kernel: 1 KiB per head each; nothing is zeroed, the consumers reduce the blocks' entries themselves).
  * This is what `_fp8_attention_wrapper` does for its two tensors at nn.py:410-418, plus the build's quantised V.
  */
 size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv);

@@ -74,8 +74,8 @@ struct AttnCall {
     unsigned* flags;   // nullptr or one word per (b, h, 32-row group) of THIS call
     const float *ssq_q, *ssq_k;   // fused step, head-wise AUTO: the heads' partial sums of squares from the pre-pass (else nullptr)
     int ssq_n;
-    const void* q16;   // fused step (else nullptr): bf16 Q, quantised in the kernel from q_amax_bits; sq_out is written
-    const unsigned* q_amax_bits;
+    const void* q16;   // fused step (else nullptr): bf16 Q, quantised in the kernel from q_amax_part; sq_out is written
+    const unsigned* q_amax_part;   // per-block abs-max words of every q head [B*Hq][kMomentSplits], ssq_n valid per head
     float* sq_out;
     int q_numerics;
 };
@@ -119,7 +119,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.flags = a.flags;
     p.lse_stride = (long)qattn_lse_row_stride(a.Sq, a.lse_layout);
     p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
-    p.q16 = (const unsigned char*)a.q16; p.q_amax_bits = a.q_amax_bits; p.sq_out = a.sq_out; p.q_numerics = a.q_numerics;
+    p.q16 = (const unsigned char*)a.q16; p.q_amax_part = a.q_amax_part; p.sq_out = a.sq_out; p.q_numerics = a.q_numerics;
     bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
 #ifdef QATTN_DEV
     const DevEnv& e = dev_env();
@@ -318,7 +318,7 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
     AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
                fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, flags,
-               moments ? mom.part_q : nullptr, moments ? mom.part_k : nullptr, mom.nsplit, fuse_q ? q : nullptr, fuse_q ? ws : nullptr, fuse_q ? scale_q : nullptr, numerics};
+               moments ? mom.part_q : nullptr, moments ? mom.part_k : nullptr, mom.nsplit, fuse_q ? q : nullptr, fuse_q ? mom.amax_q : nullptr, fuse_q ? scale_q : nullptr, numerics};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

@@ -72,7 +72,7 @@ struct AttnParams {
     long lse_stride; // floats between the LSE rows of consecutive (b, h)
     float lse_mul;   // 1 (natural log-sum-exp) or -sqrt(D) (QATTN_LSE_REFERENCE)
     const unsigned char* q16;      // fused step: the 16-bit (bf16) Q tensor, quantised row by row in the kernel prologue (else nullptr)
-    const unsigned* q_amax_bits;   // fused step: per-(b,h) abs-max bits of Q from the amax pass
+    const unsigned* q_amax_part;   // fused step: per-block abs-max words of every q head [B*Hq][ssq_stride] (ssq_n valid) from the amax pass
     float* sq_out;                 // fused step: scale_q [B,Hq] is written by the attention kernel
     int q_numerics;
 #ifdef QATTN_DEV

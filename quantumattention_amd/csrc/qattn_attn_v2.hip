@@ -657,7 +657,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     if (Q16) {
         static_assert(!Q16 || !TOKEN, "the fused Q path is head-wise");
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(p.q_amax_bits[bh]), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.ssq_stride, p.ssq_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
     }
     // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210)
@@ -725,7 +725,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     float c;
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        c = p.sm_log2e * make_scale(__uint_as_float(p.q_amax_bits[bh]), inv_qmax, p.q_numerics, QATTN_FMT_BF16) * p.sk[kv_head];
+        c = p.sm_log2e * make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.ssq_stride, p.ssq_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16) * p.sk[kv_head];
     } else {
         c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
     }

@@ -175,14 +175,23 @@ __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv
     return r;
 }
 
-// q/k/v pre-pass launcher shared by qattn_quant_qkv_fp8 and the fused step entry (qattn_api.hip).  `ws` holds the amax bits
-// of q [B*Hq], k [B*Hkv], v [B*Hkv] (zeroed here).  skip_q_payload: q8 / scale_q are not written (the attention kernel
+// the maximum of a head's per-block abs-max words, the same value in every lane
+__device__ inline unsigned max_partials(const unsigned* part, int n, int lane) {
+    unsigned m = 0u;
+    for (int i = lane; i < n; i += 64) m = max(m, part[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    return m;
+}
+
+// q/k/v pre-pass launcher shared by qattn_quant_qkv_fp8 and the fused step entry (qattn_api.hip).  `ws` holds the per-block
+// abs-max words of q [B*Hq][256], k [B*Hkv][256], v [B*Hkv][256] and the per-block sums of squares (quant_moments).  skip_q_payload: q8 / scale_q are not written (the attention kernel
 // quantises its own Q rows from the 16-bit tensor and the q amax bits).
 // want_moments (head-wise only): the abs-max pass also leaves the sums of squares of every q and k head in the workspace, as
 // `nsplit` partial sums per head (stride kMomentSplits), where quant_moments() finds them (the attention kernel's score-spread
 // estimate, qattn_attn.h predicted_r).
 constexpr int kMomentSplits = 256;   // >= the abs-max pass's blocks per head
-struct QuantMoments { const float* part_q; const float* part_k; int nsplit; };
+struct QuantMoments { const float* part_q; const float* part_k; const unsigned* amax_q; int nsplit; };
 inline int amax_splits(int Sq, int Skv, int D) {
     const long vecs = (long)(Sq > Skv ? Sq : Skv) * D / 8;
     const long s = (vecs + 2047) / 2048;   // 8 x 16 B per thread and block
@@ -190,8 +199,8 @@ inline int amax_splits(int Sq, int Skv, int D) {
 }
 inline QuantMoments quant_moments(const unsigned* ws, int B, int Hq, int Hkv, int Sq, int Skv, int D) {
     const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
-    const float* s = reinterpret_cast<const float*>(ws + nq + 2 * nk);
-    return QuantMoments{s, s + nq * kMomentSplits, amax_splits(Sq, Skv, D)};
+    const float* s = reinterpret_cast<const float*>(ws + kMomentSplits * (nq + 2 * nk));
+    return QuantMoments{s, s + nq * kMomentSplits, ws, amax_splits(Sq, Skv, D)};
 }
 int launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                      float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt, int scale_mode,

@@ -199,7 +199,7 @@ struct QuantJob {
     const uint4* x;       // [G, S, D] 16-bit
     uint4* out;           // fp8 payload
     float* scale;         // [G] (head) or [G, S] (token)
-    unsigned* amax_bits;  // [G] workspace (head-wise)
+    unsigned* amax_part;  // [G][kMomentSplits] workspace (head-wise): fp32 bits of the abs-max of every abs-max-pass block's share
     int G, S, layout, token;
     // head-wise q and k of the fused step (else nullptr): every block of the abs-max pass leaves the sum of squares of its
     // share of the head in part[g][block]; the attention kernel adds a head's partial sums in a fixed order (deterministic, no
@@ -209,6 +209,7 @@ struct QuantJob {
 };
 struct QuantJobs {
     QuantJob j[3];
+    int nsplit;           // abs-max-pass blocks per head = valid entries of amax_part / part per head
 };
 
 template <int IN_FMT>
@@ -268,8 +269,10 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; red_ss[threadIdx.x >> 6] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // no atomics and nothing to zero beforehand: the consumers (quantise pass, attention prologue) take the maximum of a
+        // head's `splits` entries themselves
         m = max(max(red[0], red[1]), max(red[2], red[3]));
-        atomicMax(jb.amax_bits + g, __float_as_uint(load16f<IN_FMT>((unsigned short)m)));
+        jb.amax_part[g * kMomentSplits + blockIdx.x] = __float_as_uint(load16f<IN_FMT>((unsigned short)m));
         if (moments) jb.part[g * kMomentSplits + blockIdx.x] = (red_ss[0] + red_ss[1]) + (red_ss[2] + red_ss[3]);
     }
 }
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
     float scale = 1.0f;
     if (!token) {
-        scale = make_scale(__uint_as_float(jb.amax_bits[g]), inv_qmax, numerics, IN_FMT);
+        scale = make_scale(__uint_as_float(max_partials(jb.amax_part + (long)g * kMomentSplits, jobs.nsplit, tid & 63)), inv_qmax, numerics, IN_FMT);
         if (tile == 0 && tid == 0) jb.scale[g] = scale;
     }
     float rinv = 1.0f / scale;
@@ -762,9 +765,9 @@ extern "C" int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, i
 
 extern "C" size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0) return 0;
-    // [abs-max bits of q, k, v (zeroed every call) | partial sums of squares of q, k: kMomentSplits per head]
+    // [per-block abs-max bits of q, k, v | per-block sums of squares of q, k]: kMomentSplits words per head each; nothing to zero
     const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
-    return ((nq + 2 * nk) + qattn::kMomentSplits * (nq + nk)) * sizeof(unsigned);
+    return qattn::kMomentSplits * ((nq + 2 * nk) + (nq + nk)) * sizeof(unsigned);
 }
 
 #ifdef QATTN_DEV
@@ -823,15 +826,15 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
                             int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, hipStream_t st) {
     const int tok = scale_mode == QATTN_SCALE_TOKEN;
     const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
-    if (hipMemsetAsync(ws, 0, (nq + 2 * nk) * sizeof(unsigned), st) != hipSuccess) return QATTN_ERR_LAUNCH;
-    float* part = reinterpret_cast<float*>(ws + nq + 2 * nk);   // q heads then k heads
+    float* part = reinterpret_cast<float*>(ws + kMomentSplits * (nq + 2 * nk));   // q heads then k heads
     const bool moments = !tok && want_moments;
     QuantJobs jobs;
+    jobs.nsplit = amax_splits(Sq, Skv, D);
     jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok,
                          moments ? part : nullptr};
-    jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + nq, B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
+    jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + kMomentSplits * nq, B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
                          moments ? part + nq * kMomentSplits : nullptr};
-    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + nq + nk, B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0, nullptr};
+    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + kMomentSplits * (nq + nk), B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0, nullptr};
     // (Tried and dropped: one tensor at a time -- amax then quantise, hoping the re-read hits the 256 MiB Infinity Cache --
     // was 13 % slower than the two fused launches; a one-pass register-resident variant with a cross-workgroup amax
     // exchange was 2-6x slower, the agent-scope atomics + spinning cost more than the second read.  A third variant --

@@ -38,9 +38,9 @@ def test_abi_size_queries_and_error_codes_need_no_gpu():
     assert L.qattn_fp8_tensor_bytes(_native.LAYOUT_VFRAG, 1, 2, 64, 64) == 2 * 64 * 64
     assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_HEAD) == 4 * 32 * 4
     assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_TOKEN) == 0
-    assert L.qattn_quant_qkv_workspace_bytes(4, 32, 8) == 4 * ((128 + 64) + 256 * 160)   # abs-max words | partial sums of squares of q and k
+    assert L.qattn_quant_qkv_workspace_bytes(4, 32, 8) == 4 * 256 * ((128 + 64) + 160)   # per-block abs-max words of q, k, v | per-block sums of squares of q and k
     assert L.qattn_attention_workspace_bytes(4, 32, 4096) == 4 * 32 * 128 * 4          # one word per 32-row query group
-    assert L.qattn_fp8_quant_attention_workspace_bytes(4, 32, 8, 4096) == 4 * ((128 + 64) + 256 * 160) + 4 * 32 * 128 * 4   # both parts multiples of 16
+    assert L.qattn_fp8_quant_attention_workspace_bytes(4, 32, 8, 4096) == 4 * 256 * ((128 + 64) + 160) + 4 * 32 * 128 * 4   # both parts multiples of 16
     assert L.qattn_lse_row_stride(1000, _native.LSE_NATURAL) == 1000
     assert L.qattn_lse_row_stride(1001, _native.LSE_REFERENCE) == 1004                 # row padded to 16 bytes (tk/attention.py:439)
     for code in range(0, -7, -1):

@@ -23,10 +23,10 @@ torch.cuda.synchronize()
 print("rc", rc)
 n = B * H
 w = ws.view(torch.int32)
-ssq = ws.view(torch.float32)[3 * n: 5 * n]
-print("amax bits q", w[:n].tolist()[:4])
+K = 256
+ssq = ws.view(torch.float32)[K * 3 * n: K * 5 * n].view(2 * n, K)[:, :8].sum(1)
+print("amax bits q", w[:K * n].view(n, K)[:, :8].max(1).values.tolist()[:4])
 print("ssq q", ssq[:n].tolist()); print("ref  ", q.float().pow(2).sum((2, 3)).flatten().tolist())
 print("ssq k", ssq[n:].tolist()); print("ref  ", k.float().pow(2).sum((2, 3)).flatten().tolist())
-print("arrived", w[5 * n: 7 * n].tolist())
 ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
 print("max err vs fp32 sdpa on unquantised", (out.float() - ref).abs().max().item())
