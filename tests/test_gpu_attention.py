@@ -84,6 +84,8 @@ CASES = [
     (1, 2, 2, 1024, 1024, 256, False, "e5m2", "token-wise", torch.bfloat16),
     (1, 4, 2, 2100, 2100, 256, True, "e4m3", "head-wise", torch.bfloat16),      # two-term + byte launches, GQA
     (2, 4, 4, 1500, 1200, 64, False, "e5m2", "head-wise", torch.float16),
+    (1, 8, 2, 1100, 1100, 128, False, "e4m3", "head-wise", torch.bfloat16),     # GQA on the hand-scheduled kernel (K/V head, moments and rescue
+    (1, 6, 3, 1300, 1300, 128, True, "e4m3", "head-wise", torch.bfloat16),      #   index the kv head), with and without the XCD remap (B*Hq % 8)
 ]
 
 

@@ -115,6 +115,25 @@ def test_heads_with_wide_scores_start_in_two_term_mode():
     assert err_stats(auto, ref)[0] < TOL
 
 
+def test_gqa_with_one_wide_kv_group():
+    """GQA through the fused step on peaked data: 8 query heads share 2 kv heads; the query heads of kv group 1 are scaled x3, so
+    the starting-mode prediction (indexed by query head and kv head), the rescue (indexed by kv head) and the redo all meet."""
+    torch.manual_seed(11)
+    S, D = 2048, 128
+    q = torch.randn(1, 8, S, D); k = torch.randn(1, 2, S, D); v = torch.randn(1, 2, S, D)
+    q[:, 4:] *= 3.0
+    q[:, 1] *= torch.linspace(0.5, 4.0, S)[torch.randperm(S)].view(S, 1)
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    from tests.gpu_utils import oracle_for_fp8_path
+    q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    for causal in (False, True):
+        ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8="e4m3", causal=causal)
+        got = _run(q, k, v, causal, "auto")
+        assert np.isfinite(got).all()
+        assert err_stats(got, ref)[0] < TOL, (causal, err_stats(got, ref))
+
+
 def test_lse_reference_layout_and_convention():
     """the reference-defined (disabled) vector, tk/attention.py:333-346 / :439-446:
     L = -(ln l + m ln2) sqrt(D), rows of consecutive (b, h) ld = ceil(Sq*4/16)*16/4 floats apart."""
