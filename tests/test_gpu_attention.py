@@ -206,6 +206,23 @@ def test_full_size_properties_B4_H32_S4096_D128(causal):
         assert (outp.float() - out[:1].float()).abs().max() < TOL
 
 
+@pytest.mark.parametrize("precision", ["auto", "fast"])
+def test_persistent_launch_equals_one_workgroup_per_block(precision):
+    """Non-causal launches with more blocks than CUs run persistent workgroups (csrc/qattn_attn_v2.hip); smaller ones one
+    workgroup per block.  B = 2 x 8 heads x 32 blocks = 512 blocks is the former, each batch element alone (256 blocks) the
+    latter: same bits.  One head is scaled so that rescues and two-term blocks occur in both forms."""
+    torch.manual_seed(21)
+    B, H, S, D = 2, 8, 8192, 128
+    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    q[:, 3] *= 1.25
+    q[:, 5] *= 2.0
+    with qa.config.patch({"attention.precision": precision}):
+        both = qa.fp8_attn_func(q, k, v)
+        for b in range(B):
+            assert torch.equal(both[b:b + 1], qa.fp8_attn_func(q[b:b + 1], k[b:b + 1], v[b:b + 1])), b
+    assert torch.isfinite(both).all()
+
+
 def test_full_size_properties_config5_shape_S16384_H40_e5m2_causal():
     """BASELINE config 5's shape and format (float8_e5m2, causal, S = 16384, 40 heads, B = 1) at full size."""
     torch.manual_seed(5)
