@@ -93,3 +93,17 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert p.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (p.stderr + p.stdout)
+
+
+def test_bench_under_torch_distributed_run_dry_run():
+    """The driver's N > 1 command line: torch.distributed.run starts the ranks, bench.py takes RANK / WORLD_SIZE from the environment."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    port = 29700 + (os.getpid() % 200)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 8
