@@ -102,9 +102,11 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.nchunks = ceil_div(a.Skv, 64);
     p.out_fmt = a.out_fmt;
     p.xcd_remap = ((a.B * a.Hq) % 8 == 0) ? 1 : 0;
+    // causal: heads taken in groups whose K + V (2 Skv D bytes of fp8 per head) stay within half of an XCD's 4 MiB L2 -- with
+    // 4 heads at S = 4096 (4 MiB) the PMC passes counted 1.3x the algorithmic HBM bytes, at S = 16384 (16 MiB) 2.4x
     p.causal_group = 1;
     for (int g = kCausalHeadGroup; g > 1; g >>= 1)
-        if (p.xcd_remap && ((a.B * a.Hq) >> 3) % g == 0) { p.causal_group = g; break; }
+        if (p.xcd_remap && ((a.B * a.Hq) >> 3) % g == 0 && (size_t)g * 2 * a.Skv * a.D <= kCausalGroupBytes) { p.causal_group = g; break; }
     const float sm = a.sm_scale > 0.0f ? a.sm_scale : 1.0f / sqrtf((float)a.D);
     p.sm_log2e = sm * 1.4426950408889634f;
     p.precision = a.precision;

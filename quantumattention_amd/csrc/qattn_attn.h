@@ -156,8 +156,9 @@ __device__ inline void wait_vmcnt() {
 // each XCD gets a contiguous range of heads so the heads it works on keep their K/V in its private 4 MiB L2.
 // Causal: query blocks differ 16:1 in work, so within an XCD the heads are taken in groups of kCausalHeadGroup and a
 // group's blocks are issued heaviest first ACROSS its heads (longest-processing-time order: the launch ends on the lightest
-// blocks instead of on a late heavy one); 4 heads x (K + V) = 4 MiB at S = 4096, D = 128 still fit the XCD's L2.
+// blocks instead of on a late heavy one), as long as the group's K + V fit kCausalGroupBytes of the XCD's L2.
 constexpr int kCausalHeadGroup = 4;
+constexpr size_t kCausalGroupBytes = 2u << 20;
 __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool causal, int& head, int& qb) {
     if (p.xcd_remap) {
         const int xcd = bid & 7, idx = bid >> 3, hpx = (p.B * p.Hq) >> 3;

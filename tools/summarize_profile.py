@@ -17,7 +17,8 @@ causal = len(sys.argv) >= 8 and sys.argv[7] not in ("0", "false")
 os.makedirs(dst, exist_ok=True)
 csv.field_size_limit(1 << 30)
 
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+newest = lambda paths: sorted(paths, key=os.path.getmtime)[-1:]   # gpurun merges runs into one directory: keep the latest of each pass
+stats = newest(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True))
 if stats:
     with open(stats[0]) as f, open(os.path.join(dst, "kernel_stats.csv"), "w") as g:
         for i, line in enumerate(f):
@@ -25,7 +26,8 @@ if stats:
                 g.write(line)
 
 summary = {}
-for cc in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+for cc in [f for d in sorted(glob.glob(os.path.join(src, "pmc_*"))) if os.path.isdir(d)
+           for f in newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))]:
     acc = {}
     with open(cc) as f:
         for row in csv.DictReader(f):
