@@ -214,7 +214,7 @@ def run_rank(args):
         "value": None, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": f"fp8_{args.fp8} (fp32 accumulate)", "data": "synthetic", "ranks_seen": ranks_seen,
-        "settle_steps": settle_steps,
+        "settle_steps": settle_steps, "device": (torch.cuda.get_device_name(local_rank) if not dry else "cpu (dry run)"),
         "config": {"workload": f"B={B} H={H} S={S} D={D} {'causal' if args.causal else 'non-causal'} fp8({args.fp8}) "
                                f"per GPU, bf16 in/out, head-wise scales, precision={args.precision} (BASELINE.json configs[1]"
                                f"{'; batch-sharded B=%d total, configs[3] at 8 GPUs' % (B * world) if world > 1 else ''})",

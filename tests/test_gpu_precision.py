@@ -134,6 +134,28 @@ def test_gqa_with_one_wide_kv_group():
         assert err_stats(got, ref)[0] < TOL, (causal, err_stats(got, ref))
 
 
+def test_non_finite_and_degenerate_heads_do_not_disturb_the_others():
+    """A head of zeros, a head with an inf, a head with a NaN and a head of huge values go through the fused step next to normal
+    heads: the moments of such heads are 0 / inf / NaN (the starting-mode prediction must not trip on them), the normal heads'
+    rows must come out exactly as when they are attended alone, and the call must return."""
+    torch.manual_seed(13)
+    S, D = 1536, 128
+    q, k, v = (torch.randn(1, 8, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    q[0, 1] = 0
+    q[0, 2, 5, 7] = float("inf")
+    k[0, 3, 9, 1] = float("nan")
+    q[0, 4] *= 1.0e18
+    k[0, 4] *= 1.0e18
+    for causal in (False, True):
+        out = qa.fp8_attn_func(q, k, v, is_causal=causal)
+        torch.cuda.synchronize()
+        for h in (0, 5, 6, 7):
+            alone = qa.fp8_attn_func(q[:, h:h + 1], k[:, h:h + 1], v[:, h:h + 1], is_causal=causal)
+            assert torch.equal(out[:, h:h + 1], alone), (causal, h)
+            assert torch.isfinite(out[:, h]).all()
+        assert torch.isfinite(out[:, 1]).all()          # zero queries: uniform attention, finite
+
+
 def test_lse_reference_layout_and_convention():
     """the reference-defined (disabled) vector, tk/attention.py:333-346 / :439-446:
     L = -(ln l + m ln2) sqrt(D), rows of consecutive (b, h) ld = ceil(Sq*4/16)*16/4 floats apart."""
