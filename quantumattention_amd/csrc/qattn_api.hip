@@ -143,6 +143,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     if (e.variant == 4) use_v2 = false;
     if (e.causal_group > 0 && p.xcd_remap && ((a.B * a.Hq) >> 3) % e.causal_group == 0) p.causal_group = e.causal_group;
 #endif
+    p.peak_z = (float)p.two_term_keys > kPeakR0 ? 0.5f + logf((float)p.two_term_keys / kPeakR0) : 0.0f;   // see predicted_r
     const bool prof = ds != nullptr;
     if (prof) (void)hipEventRecord(ds->prof[0], st);
     int rc;
@@ -313,7 +314,7 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     // them instead of sharing the CU, and the chip is power-limited on the attention kernel: the step got 19-31 % SLOWER.)
     unsigned* ws = (unsigned*)workspace;
     unsigned* flags = (unsigned*)((unsigned char*)workspace + (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16);
-    const bool moments = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
+    const bool moments = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD;
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
                               numerics, ws, fuse_q, moments, st);
     if (rc != QATTN_OK) return rc;

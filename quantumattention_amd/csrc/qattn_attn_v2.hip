@@ -861,7 +861,6 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     // blocks that run two-term P from the start: every block (QATTN_PRECISION_ACCURATE), else the kernel's predicted_r rule
     // (at unit score variance: the blocks whose first row sees fewer than kTwoTermKeys keys)
     p.n_two = p.precision == QATTN_PRECISION_ACCURATE ? p.nqb : 0;
-    p.peak_z = (float)p.two_term_keys > kPeakR0 ? 0.5f + logf((float)p.two_term_keys / kPeakR0) : 0.0f;
 #ifdef QATTN_DEV
     if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])

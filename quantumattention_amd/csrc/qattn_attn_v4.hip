@@ -63,6 +63,19 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     const long bh = (long)b * p.Hq + h;
     const int ng = (p.Sq + 31) >> 5;          // 32-row groups per head
     unsigned* flag = p.flags ? p.flags + bh * ng + (q0 >> 5) : nullptr;   // this wave's group
+    if (mode == 0 && flag != nullptr && p.ssq_q != nullptr) {
+        // AUTO in the fused step: a head whose predicted score spread makes its rows end below kPeakR0 anyway (predicted_r,
+        // qattn_attn.h) is not swept with one-term P first: its groups are flagged, the redo launch attends them in two-term mode
+        const int kvh = (int)kv_head;
+        float var = sum_partials(p.ssq_q + bh * p.ssq_stride, p.ssq_n, lane) * sum_partials(p.ssq_k + (long)kvh * p.ssq_stride, p.ssq_n, lane) * p.var_mul;
+        if (var >= kVarDeadband) {
+            const int nkeys = CAUSAL ? min(p.Skv, q0_wg + 1) : p.Skv;
+            if (__builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, p.peak_z) < kPeakR0 ? 1 : 0)) {
+                if (lane == 0 && q0 < p.Sq) *flag = 1u;
+                return;
+            }
+        }
+    }
     if (only_flagged) {  // workgroup-uniform: count the flagged groups of the 256-row block these rows belong to
         const int g0 = (q0_wg >> 8) << 3;
         int nf = 0;

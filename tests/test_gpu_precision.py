@@ -98,13 +98,14 @@ def test_flat_rows_keep_the_one_term_result_bit_for_bit():
     assert err_stats(f[:1, :2], ref)[0] < TOL      # the unchecked one-term path is accurate on flat rows
 
 
-def test_heads_with_wide_scores_start_in_two_term_mode():
+@pytest.mark.parametrize("D", [128, 64, 256])
+def test_heads_with_wide_scores_start_in_two_term_mode(D):
     """The fused step hands the attention kernel every head's sum of squares (abs-max pass, deterministic partial sums); a head
     whose predicted score variance is clearly above 1 starts its blocks in two-term mode instead of sweeping once in vain
-    (qattn_attn.h predicted_r).  Observable without a clock: for such a head AUTO must return ACCURATE's bits, for a
+    (qattn_attn.h predicted_r; D = 64 / 256: its groups are flagged unswept and the two-term redo launch takes them).  Observable without a clock: for such a head AUTO must return ACCURATE's bits, for a
     unit-variance head (below the dead band) it must not -- there the one-term result stands."""
     torch.manual_seed(5)
-    S, D = 2048, 128
+    S = 2048
     q, k, v = (torch.randn(1, 2, S, D) for _ in range(3))
     q[:, 1] *= 2.0                                            # head 0: score std 1, head 1: score std 2
     q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
