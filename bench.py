@@ -311,7 +311,15 @@ def run_rank(args):
                 # wait inside the run: the events are read after the last window)
                 evs, t_end = [torch.cuda.Event(enable_timing=True)], time.perf_counter() + 2.0
                 evs[0].record()
-                while time.perf_counter() < t_end or len(evs) < 6:
+                smi = None
+                try:   # socket power and shader clock while the queue is full (read-only rocm-smi, a child process: ~0.5 s)
+                    for _ in range(400):
+                        step()
+                    smi = subprocess.Popen(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], stdout=subprocess.PIPE,
+                                           stderr=subprocess.DEVNULL, text=True)
+                except Exception:
+                    smi = None
+                while time.perf_counter() < t_end or len(evs) < 6 or (smi is not None and smi.poll() is None and time.perf_counter() < t_end + 10):
                     for _ in range(20):
                         step()
                     evs.append(torch.cuda.Event(enable_timing=True))
@@ -322,6 +330,17 @@ def run_rank(args):
                 windows = sorted(a.elapsed_time(b) / 20 for a, b in zip(evs[:-1], evs[1:]))
                 line["sustained_ms_per_step"] = windows[len(windows) // 2]
                 line["sustained_windows"] = len(windows)
+                if smi is not None:
+                    try:
+                        txt = smi.communicate(timeout=20)[0]
+                        import re
+                        grab = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, txt))
+                        line["under_load"] = {"socket_power_w": grab(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)"),
+                                              "power_cap_w": grab(r"Max Graphics Package Power \(W\): ([0-9.]+)"),
+                                              "sclk_mhz": grab(r"sclk clock level: \S+ \(([0-9.]+)Mhz\)"),
+                                              "source": "rocm-smi, sampled while the sustained run keeps the queue full"}
+                    except Exception:
+                        pass
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
             def extra(Bx, Hx, Sx, causal, fp8, n):
                 qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
