@@ -114,6 +114,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.peak_r0 = a.precision == QATTN_PRECISION_AUTO ? kPeakR0 : 0.0f;
     p.max_rescue = kMaxRescueWaves;
     p.persistent = 1;
+    p.no_forecast = 0;
     p.ssq_q = a.precision == QATTN_PRECISION_AUTO ? a.ssq_q : nullptr;   // (FAST: the caller vouches for flat rows)
     p.ssq_k = p.ssq_q ? a.ssq_k : nullptr;
     p.ssq_n = a.ssq_n; p.ssq_stride = kMomentSplits;
@@ -130,6 +131,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = e.peak_r0;
     if (getenv("QATTN_MAX_RESCUE")) p.max_rescue = atoi(getenv("QATTN_MAX_RESCUE"));
     if (getenv("QATTN_PERSISTENT")) p.persistent = atoi(getenv("QATTN_PERSISTENT"));
+    if (getenv("QATTN_NO_FORECAST")) p.no_forecast = atoi(getenv("QATTN_NO_FORECAST"));
     p.waves = !use_v2 ? kWaves : e.waves;
     p.nqb = ceil_div(a.Sq, p.waves * kQPerWave);
     p.lds_pad = e.lds; p.dbg = e.dbg; p.dbg_buf = nullptr;

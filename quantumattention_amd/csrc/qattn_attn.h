@@ -28,6 +28,11 @@ constexpr float kPeakR0 = 24.0f;
 // below kVarDeadband count as 1: unit-variance data takes the same decisions with and without the moments, so the fused step
 // and the quantise-then-attend sequence of C calls stay bit-identical there.
 constexpr float kVarDeadband = 1.5f;
+// A head (or a wave's sample of scores) that IS wide is judged with a larger z: what decides a block's fate is whether more
+// than max_rescue of its 32-row groups hold a flagged row, and with the row-to-row variation of |q| that happens from a
+// score spread of about 1.2 on at n = 4096 (measured: q x 1.15 a fifth of the blocks repeat, q x 1.25 nearly all):
+// 4096 exp(1.2^2 / 2 - z 1.2) = 24 at z = 4.9.
+constexpr float kPeakZWide = 4.9f;
 __device__ inline float predicted_r(float nkeys, float var, float z) { return nkeys * __expf(0.5f * var - z * sqrtf(var)); }
 // a head's sum of squares from its partial sums, the same value in every lane of every wave (fixed order: lane l adds
 // l, l + 64, ...; then the xor tree)
@@ -67,6 +72,7 @@ struct AttnParams {
     float var_mul;               // score variance of head (bh, kvh) ~= sum(ssq_q[bh]) * sum(ssq_k[kvh]) * var_mul
     int total_blocks;            // B * Hq * nqb (set by the launcher); the grid may be smaller: workgroups walk blocks bid, bid + gridDim.x, ...
     int persistent;              // one workgroup per CU instead of one per block
+    int no_forecast;             // dev switch
     int max_rescue;              // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
     unsigned* flags; // templated kernel (qattn_attn_v4.hip): one word per (head, 32-row group), set by the one-term launch
     long lse_stride; // floats between the LSE rows of consecutive (b, h)

@@ -358,11 +358,19 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     QATTN2_STAMP(3);
 }
 
-// The KV sweep of one wave.  Returns with st.o / st.l_run / st.m_run final.
+// The KV sweep of one wave.  Returns false with st.o / st.l_run / st.m_run final.
+// `forecast` (one-term byte-exponential passes under QATTN_PRECISION_AUTO): every wave measures the variance of its 32 x 64
+// scores of the first chunk and predicts the smallest R = l / p_max of its rows from it (predicted_r with kPeakZWide: 2048
+// samples, so the measured spread includes what an isotropic moment estimate misses -- a few large dimensions in q and k --
+// and callers without moments get it too); when more waves than max_rescue predict a row below the threshold, the block is
+// going to be repeated in two-term mode anyway: after two more chunks (the votes travel through the sweep's own barrier) all
+// waves drain the ring, stop and return true -- 3 of n chunks wasted instead of all of them.  Chunk 0 stands for the whole
+// key range here; where it does not, the R test at the end of the sweep is still the arbiter.
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, typename LoadQ>
-__device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
+__device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
-                                         int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q) {
+                                         int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q,
+                                         bool forecast = false, unsigned* vote = nullptr) {
     constexpr int CH = 64 * D, STAGE = 2 * CH;
     const int hh = lane >> 5;
     const int T = n_wg + 2;  // iterations t = 0 .. n_wg+1 : QK(t), softmax(t-1), PV(t-2)
@@ -464,6 +472,47 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
+    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && ABL == 0;
+#ifdef QATTN_DEV
+    if (p.no_forecast) forecast = false;   // QATTN_NO_FORECAST=1: A/B switch
+#endif
+    // every wave of the workgroup runs the first two iterations (causal: wave 0 has the fewest chunks) and the sweep is long enough to matter
+    const int n_w0 = CAUSAL ? min(n_wg, (q0 - wave * kQPerWave + kQPerWave - 1) / 64 + 1) : n_w;
+    forecast = FORECAST && forecast && n_w0 >= 3 && n_wg >= 16;
+    if constexpr (FORECAST) {
+        if (forecast) {
+            // spread of the wave's 32 x 64 scores of chunk 0 (all visible: causal blocks past the first), in natural-log units
+            float su = 0.0f, sq = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                su += st.s[0][0][r] + st.s[0][1][r];
+                sq = __builtin_fmaf(st.s[0][0][r], st.s[0][0][r], __builtin_fmaf(st.s[0][1][r], st.s[0][1][r], sq));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { su += __shfl_xor(su, off); sq += __shfl_xor(sq, off); }
+            const float mean = su * (1.0f / 2048.0f), cn = st.c * 0.6931471805599453f;
+            const float var = fmaxf(sq * (1.0f / 2048.0f) - mean * mean, 0.0f) * cn * cn;
+            const int nkeys = CAUSAL ? min(p.Skv, q0 + kQPerWave) : p.Skv;
+            // (below the dead band the block already started in the right mode: borderline causal rows are cheaper to rescue)
+            const bool mine = var >= kVarDeadband && predicted_r((float)nkeys, var, kPeakZWide) < kPeakR0;   // the same value in every lane
+            if (lane == 0) vote[wave] = mine ? 1u : 0u;
+        }
+    }
+    if constexpr (FORECAST) {
+        if (forecast) {   // (n_w >= 3 here) the first pair of iterations, peeled so that the loop below stays free of the test
+            full(P1{}, 1);
+            full(P0{}, 2);   // starts with the barrier that publishes the votes
+            t = 3;
+            int nf = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) nf += vote[w] != 0u ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(nf) > p.max_rescue) {
+                wait_vmcnt<0>();   // the stages requested at that barrier
+                __builtin_amdgcn_s_barrier();
+                return true;
+            }
+        }
+    }
     for (; t + 1 <= n_w; t += 2) {
         full(P1{}, t);
         full(P0{}, t + 1);
@@ -500,6 +549,7 @@ __device__ __forceinline__ void kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // causal: waves whose rows end earlier keep the workgroup's barrier / DMA cadence until the last wave is done
     for (; t < T; ++t) sync_iter(t);
+    return false;
 }
 
 // One pass of a wave over its KV range with P in TWO (hi + lo) or one term, BYTE-exponential or exact, followed by the
@@ -537,7 +587,9 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
         }
     };
-    kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags);
+    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
+                                                                            !TWO && check_peaked, vote))
+        return kPassRedo;   // forecast: the block is peaked, nothing was stored
 #ifdef QATTN_DEV
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -754,7 +806,8 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
             if (!(var >= kVarDeadband)) var = 1.0f;
         }
         const int nkeys = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;   // keys the block's first row attends
-        two = __builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, p.peak_z) < kPeakR0 ? 1 : 0) != 0;   // (every lane holds the same value)
+        const float z = var >= kVarDeadband ? fmaxf(p.peak_z, kPeakZWide) : p.peak_z;
+        two = __builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, z) < kPeakR0 ? 1 : 0) != 0;   // (every lane holds the same value)
     }
     int tid = threadIdx.x;
 #ifdef QATTN_DEV

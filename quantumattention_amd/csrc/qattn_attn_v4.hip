@@ -70,7 +70,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
         float var = sum_partials(p.ssq_q + bh * p.ssq_stride, p.ssq_n, lane) * sum_partials(p.ssq_k + (long)kvh * p.ssq_stride, p.ssq_n, lane) * p.var_mul;
         if (var >= kVarDeadband) {
             const int nkeys = CAUSAL ? min(p.Skv, q0_wg + 1) : p.Skv;
-            if (__builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, p.peak_z) < kPeakR0 ? 1 : 0)) {
+            if (__builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, fmaxf(p.peak_z, kPeakZWide)) < kPeakR0 ? 1 : 0)) {
                 if (lane == 0 && q0 < p.Sq) *flag = 1u;
                 return;
             }

@@ -116,6 +116,25 @@ def test_heads_with_wide_scores_start_in_two_term_mode(D):
     assert err_stats(auto, ref)[0] < TOL
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_anisotropic_heads_take_the_forecast_exit(causal):
+    """Two dimensions of q and k carry 3x the amplitude: the pre-pass's isotropic moment estimate says score variance 1.27 (inside
+    the dead band), the true one is 2.25.  The one-term sweep measures the spread of its first chunk of scores, stops after three
+    chunks and the block repeats in two-term mode (kv_sweep `forecast`): same bound as everywhere, and for a head in which every
+    block takes that exit AUTO returns ACCURATE's bits."""
+    torch.manual_seed(17)
+    S, D = 4096, 128
+    q, k, v = (torch.randn(1, 2, S, D) for _ in range(3))
+    q[..., :2] *= 3.0
+    k[..., :2] *= 3.0
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    ref = _oracle(q, k, v, causal)
+    auto, acc = _run(q, k, v, causal, "auto"), _run(q, k, v, causal, "accurate")
+    assert err_stats(auto, ref)[0] < TOL and err_stats(acc, ref)[0] < TOL
+    if not causal:
+        np.testing.assert_array_equal(auto, acc)
+
+
 def test_gqa_with_one_wide_kv_group():
     """GQA through the fused step on peaked data: 8 query heads share 2 kv heads; the query heads of kv group 1 are scaled x3, so
     the starting-mode prediction (indexed by query head and kv head), the rescue (indexed by kv head) and the redo all meet."""
