@@ -148,6 +148,11 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     const float c8 = (8.0f * U16) * c;
     const int frag_lane_off = (hh << 10) + (ql << 4);
 
+    // AUTO, one-term launch: first-chunk score-variance forecast (see kv_sweep in qattn_attn_v2.hip): every wave votes after
+    // chunk 0; if the workgroup's share of a 256-row block is going to be flagged anyway, its groups are flagged now and the
+    // two-term redo launch attends them -- 2 of n chunks spent instead of all.
+    unsigned* vote = reinterpret_cast<unsigned*>(smem + kStages4 * STAGE + NW * kQPerWave * D);
+    const bool forecast = mode == 0 && flag != nullptr && p.peak_r0 > 0.0f && n_wg >= 16 && (!CAUSAL || q0_wg >= 64);
     for (int t = 0; t < n_wg; t++) {
         // Q^T fragments do not depend on the stage: request them before the barrier so their LDS latency hides behind it
         v8i qf[KS];
@@ -155,6 +160,15 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
         for (int s = 0; s < KS; s++) qf[s] = lds_read_frag(qbuf + (s << 11));
         wait_vmcnt<0>();                  // this wave's pieces of stage t have landed
         __builtin_amdgcn_s_barrier();     // ... and everyone's; every wave is also done with stage t-1's slot
+        if (forecast && t == 1) {   // workgroup-uniform
+            int nf = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) nf += vote[w] != 0u ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(nf) * 8 > kMaxRescueWaves * NW) {
+                if (lane == 0 && q0 < p.Sq) *flag = 1u;
+                return;   // (no LDS-DMA of this wave is in flight: stage 1 was waited for above, stage 2 is not requested yet)
+            }
+        }
         if (t + 1 < n_wg) dma_next();
         if (t >= n_w) continue;           // causal: this wave's rows end before chunk t (it keeps the barrier / DMA cadence)
         const unsigned char* kbuf = smem + (t & 1) * STAGE + frag_lane_off;
@@ -192,6 +206,22 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
                 v16f& sx = (r >> 4) ? s1 : s0;
                 sx[r & 15] = dead ? -INFINITY : sx[r & 15];
             }
+        }
+        if (forecast && t == 0) {
+            float su = 0.0f, sq2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                su += s0[r] + s1[r];
+                sq2 = __builtin_fmaf(s0[r], s0[r], __builtin_fmaf(s1[r], s1[r], sq2));
+            }
+            su *= c; sq2 *= c * c;   // log2-domain scores (token-wise: c carries the row's scale)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { su += __shfl_xor(su, off); sq2 += __shfl_xor(sq2, off); }
+            const float mean = su * (1.0f / 2048.0f), ln2 = 0.6931471805599453f;
+            const float var = fmaxf(sq2 * (1.0f / 2048.0f) - mean * mean, 0.0f) * ln2 * ln2;
+            const int nkeys = CAUSAL ? min(p.Skv, q0 + kQPerWave) : p.Skv;
+            const bool mine = var >= kVarDeadband && predicted_r((float)nkeys, var, kPeakZWide) < kPeakR0;
+            if (lane == 0) vote[wave] = mine ? 1u : 0u;
         }
         // ---- running max; rescale only when a row's max grew past the headroom of the shifted exponent
         float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
@@ -302,7 +332,7 @@ static int launch_v4_one(const AttnParams& p, int row_lo, int row_hi, int mode, 
     const int qb_lo = row_lo / ROWS, qb_n = ceil_div(min(row_hi, p.Sq), ROWS) - qb_lo;
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
-    const size_t lds = (size_t)kStages4 * (2 * 64 * D + (TOKEN ? 256 : 0)) + (size_t)NW * kQPerWave * D;  // K/V ring (+ key scales) + parked Q^T fragments
+    const size_t lds = (size_t)kStages4 * (2 * 64 * D + (TOKEN ? 256 : 0)) + (size_t)NW * kQPerWave * D + 64;  // K/V ring (+ key scales) + parked Q^T fragments + forecast votes
     auto kern = attn_fwd_kernel_v4<D, FMT, FMT, CAUSAL, TOKEN, BYTE>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n, mode);
