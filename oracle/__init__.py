@@ -117,6 +117,34 @@ def quantize_fp8(x_bits: np.ndarray, in_fmt: int, scale_mode: str = "head", fmt:
     return out, scale
 
 
+def quantize_v_block(v_bits: np.ndarray, in_fmt: int, fmt: int = FMT_E4M3):
+    """The build's block-scaled V (csrc/qattn_common.h vblock_exponent; the reference keeps V in 16 bit, tk/attention.py:286,318):
+    every 64-key chunk of a head gets the power-of-two scale 2^e, e the smallest exponent with amax / 2^e <= fmax, found from the
+    fp32 bits of the chunk's abs-max in integer arithmetic (amax = m 2^k, fmax = 1.75 2^Q: e = k - Q, one more if m > 1.75; zero,
+    subnormal and non-finite abs-max: e = 0), and its elements are RNE-converted to fp8 after the exact division by 2^e.
+
+    Returns (payload uint8 [B,H,S,D], E8M0 bytes uint8 [B,H,ceil(S/64)], the de-quantised tensor as bf16 bits [B,H,S,D] --
+    fp8 x 2^e is exact in bf16, so attention_forward(..., v=those bits, v_fmt=FMT_BF16) attends exactly what the kernel does)."""
+    x = _c(v_bits, np.uint16)
+    B, H, S, D = x.shape
+    f = (bf16_bits_to_f32(x) if in_fmt == FMT_BF16 else fp16_bits_to_f32(x)).astype(np.float32)
+    nch = (S + 63) // 64
+    pad = np.zeros((B, H, nch * 64, D), np.float32)
+    pad[:, :, :S] = f
+    ch = pad.reshape(B, H, nch, 64 * D)
+    mag = np.abs(ch)
+    amax = np.where(np.isnan(mag).any(-1), np.float32(np.nan), mag.max(-1)).astype(np.float32)   # a NaN in the chunk wins (packed integer max)
+    bits = amax.view(np.uint32).astype(np.int64)
+    ef = (bits >> 23) & 255
+    e = ef - 127 - (8 if fmt == FMT_E4M3 else 15) + ((bits & 0x7FFFFF) > 0x600000)
+    e = np.clip(np.where((ef == 0) | (ef == 255), 0, e), -126, 126).astype(np.int64)
+    scale = np.ldexp(np.float32(1.0), e).astype(np.float32)[..., None]
+    qmax = np.float32(448.0 if fmt == FMT_E4M3 else 57344.0)
+    payload = f32_to_fp8(np.clip((ch / scale).astype(np.float32), -qmax, qmax), fmt).reshape(B, H, nch * 64, D)[:, :, :S]   # (clip keeps NaN)
+    deq = (fp8_to_f32(payload, fmt).reshape(B, H, S, D) * np.repeat(scale, 64, axis=2).reshape(B, H, nch * 64, 1)[:, :, :S]).astype(np.float32)
+    return payload, (e + 127).astype(np.uint8), f32_to_bf16_bits(deq)
+
+
 def attention_forward(q, k, v, q_fmt, k_fmt, v_fmt, scale_q=None, scale_k=None, scale_v=None,
                       scale_mode: str = "head", causal: bool = False, sm_scale: float = 0.0,
                       return_lse: bool = False):

@@ -72,6 +72,7 @@ struct AttnCall {
     float sm_scale;
     int precision, lse_layout;
     unsigned* flags;   // nullptr or one word per (b, h, 32-row group) of THIS call
+    const unsigned* vexp;         // fused step with a block-scaled V (else nullptr)
     const float *ssq_q, *ssq_k;   // fused step, head-wise AUTO: the heads' partial sums of squares from the pre-pass (else nullptr)
     int ssq_n;
     const void* q16;   // fused step (else nullptr): bf16 Q, quantised in the kernel from q_amax_part; sq_out is written
@@ -117,6 +118,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.no_forecast = 0;
     p.ssq_q = a.precision == QATTN_PRECISION_AUTO ? a.ssq_q : nullptr;   // (FAST: the caller vouches for flat rows)
     p.ssq_k = p.ssq_q ? a.ssq_k : nullptr;
+    p.vexp = a.vexp;
     p.ssq_n = a.ssq_n; p.ssq_stride = kMomentSplits;
     p.var_mul = sm * sm / ((float)a.Sq * (float)a.Skv * (float)a.D);
     p.flags = a.flags;
@@ -284,7 +286,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
     if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
     AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
-               is_causal, sm_scale, precision, lse_layout, have_ws ? (unsigned*)workspace : nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
+               is_causal, sm_scale, precision, lse_layout, have_ws ? (unsigned*)workspace : nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
     return attention_impl(a, (hipStream_t)stream, ds);
 }
@@ -317,13 +319,20 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     unsigned* ws = (unsigned*)workspace;
     unsigned* flags = (unsigned*)((unsigned char*)workspace + (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16);
     const bool moments = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD;
+    // block-scaled V where the hand-scheduled kernel runs (its PV products take the chunk's scale byte) and a head has at most
+    // kMomentSplits chunks: V then needs no abs-max pass
+#ifdef QATTN_DEV
+    const bool v_block = fuse_q && (Skv + 63) / 64 <= kMomentSplits && !getenv("QATTN_NO_VBLOCK");
+#else
+    const bool v_block = fuse_q && (Skv + 63) / 64 <= kMomentSplits;
+#endif
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
-                              numerics, ws, fuse_q, moments, st);
+                              numerics, ws, fuse_q, moments, v_block, st);
     if (rc != QATTN_OK) return rc;
     const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
     AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
                fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, flags,
-               moments ? mom.part_q : nullptr, moments ? mom.part_k : nullptr, mom.nsplit, fuse_q ? q : nullptr, fuse_q ? mom.amax_q : nullptr, fuse_q ? scale_q : nullptr, numerics};
+               v_block ? mom.vexp : nullptr, moments ? mom.part_q : nullptr, moments ? mom.part_k : nullptr, mom.nsplit, fuse_q ? q : nullptr, fuse_q ? mom.amax_q : nullptr, fuse_q ? scale_q : nullptr, numerics};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

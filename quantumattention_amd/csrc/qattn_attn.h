@@ -33,6 +33,7 @@ constexpr float kVarDeadband = 1.5f;
 // score spread of about 1.2 on at n = 4096 (measured: q x 1.15 a fifth of the blocks repeat, q x 1.25 nearly all):
 // 4096 exp(1.2^2 / 2 - z 1.2) = 24 at z = 4.9.
 constexpr float kPeakZWide = 4.9f;
+constexpr int kVxWords = 256;                // V chunk scale bytes a block keeps in LDS (block-scaled V: Skv <= 16384)
 __device__ inline float predicted_r(float nkeys, float var, float z) { return nkeys * __expf(0.5f * var - z * sqrtf(var)); }
 // a head's sum of squares from its partial sums, the same value in every lane of every wave (fixed order: lane l adds
 // l, l + 64, ...; then the xor tree)
@@ -73,6 +74,7 @@ struct AttnParams {
     int total_blocks;            // B * Hq * nqb (set by the launcher); the grid may be smaller: workgroups walk blocks bid, bid + gridDim.x, ...
     int persistent;              // one workgroup per CU instead of one per block
     int no_forecast;             // dev switch
+    const unsigned* vexp;        // fused step with a block-scaled V (else nullptr): E8M0 byte of every 64-key V chunk, [B*Hkv][ssq_stride]
     int max_rescue;              // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
     unsigned* flags; // templated kernel (qattn_attn_v4.hip): one word per (head, 32-row group), set by the one-term launch
     long lse_stride; // floats between the LSE rows of consecutive (b, h)
@@ -88,6 +90,14 @@ struct AttnParams {
     int dbg;         // 16 = stamp per-wave sweep cycles into dbg_buf
 #endif
 };
+
+// PV product with a block-scaled V: `scale_a` is the E8M0 byte (e + 127) of the V chunk in A (one value for both 32-wide K
+// blocks of every row here; profiles/r02_mfma_scale_probe.log), B = P unscaled.  VS = false: the plain product.
+template <int CBSZ, int BLGP, bool VS>
+__device__ inline v16f mfma_pv(v8i a, v8i b, v16f c, int scale_a) {
+    if constexpr (VS) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, CBSZ, BLGP, 0, scale_a, 0, 127);
+    else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, CBSZ, BLGP, 0, 0, 0, 0);
+}
 
 template <int CBSZ, int BLGP>
 __device__ inline v16f mfma_f8(v8i a, v8i b, v16f c) {
@@ -238,7 +248,8 @@ constexpr int rescue_slot_bytes() { return ((D / 32) * 16 + 2) * 64 * 4; }   // 
 
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QLDS = false, typename QFrag>
 __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
-                                            int r0, int wave, int lane, long bh, long kv_head, float c, const float* skt, QFrag&& qfrag) {
+                                            int r0, int wave, int lane, long bh, long kv_head, float c, const float* skt, QFrag&& qfrag,
+                                            const unsigned* vx = nullptr) {   // vx: the V chunks' scale bytes (LDS), nullptr: unscaled V
     static_assert(NW == 8, "three merge rounds");
     constexpr int CH = 64 * D, KS = D / 64, MB = D / 32;
     constexpr int SLOT = rescue_slot_bytes<D>();
@@ -294,6 +305,7 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
         v8i vf[VB];
 #pragma unroll
         for (int m = 0; m < VB; m++) vf[m] = gload_frag(vc + (m << 11));   // in flight under the softmax
+        const int vsx = vx ? (int)vx[min(t, kVxWords - 1)] : 127;
         prep_scores<CAUSAL, TOKEN>(s0, s1, p, t * 64, r0, row, hh, skt);
         float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
 #pragma unroll
@@ -342,8 +354,13 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
             }
 #pragma unroll
             for (int m = 0; m < VB; m++) {
-                o[m0 + m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], ph, o[m0 + m]);
-                o[m0 + m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], pl, o[m0 + m]);
+                if constexpr (QLDS) {   // (the D = 128 kernel's call: V may be block-scaled)
+                    o[m0 + m] = mfma_pv<V_FMT, QATTN_FMT_E4M3, true>(vf[m], ph, o[m0 + m], vsx);
+                    o[m0 + m] = mfma_pv<V_FMT, QATTN_FMT_E4M3, true>(vf[m], pl, o[m0 + m], vsx);
+                } else {
+                    o[m0 + m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], ph, o[m0 + m]);
+                    o[m0 + m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf[m], pl, o[m0 + m]);
+                }
             }
         }
     }

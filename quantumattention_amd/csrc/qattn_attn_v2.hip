@@ -100,6 +100,7 @@ struct WaveState {
     v8i qreg[2];   // QREG kernels: the wave's Q^T fragments (both k-steps) held in registers instead of re-read from LDS
     v8i ones;      // BYTE mode: the all-ones A operand of that MFMA, kept opaque so it is not re-materialised every iteration
     float c;       // scale_q*scale_k*sm_scale*log2(e)
+    int vsx;       // block-scaled V: E8M0 byte of the V chunk the current iteration's PV products read (127 = 2^0)
 #ifdef QATTN_DEV
     unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
     unsigned long long tlast;
@@ -236,7 +237,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // bandwidth, are the scarce resource at two waves per SIMD).
 //   kbuf  : stage(t),   K part  (+ lane offset)      vprev : stage(t-1), V part = V(t-2)
 //   vnext : stage(t),   V part = V(t-1) (prefetch for the next iteration)
-template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, typename Stage>
+template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, typename Stage>
 __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const unsigned char* kbuf, const unsigned char* vprev,
                                           const unsigned char* vnext, const unsigned char* qbuf, Stage&& stage) {
     static_assert(D == 128, "hand-placed slots are written for D = 128");
@@ -261,8 +262,8 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     float acc[4];
 
     // slot 0: O0 += V0.P(t-2)            reads: V2            VALU: max over tile 0
-    st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], pp, st.o[0]);
-    if (TWO) st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], ppl, st.o[0]);
+    st.o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[0], pp, st.o[0], st.vsx);
+    if (TWO) st.o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[0], ppl, st.o[0], st.vsx);
     v8i fc = LDSF(vprev + (2 << 11));
     // (v_max3_f32 through asm: on MFMA results the compiler otherwise adds a canonicalising v_max_f32 x, x, x per chain)
     float mx = max3_raw(sc0[0], sc0[1], sc0[2]);
@@ -270,8 +271,8 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     for (int r = 3; r < 15; r += 2) mx = max3_raw(mx, sc0[r], sc0[r + 1]);
     QATTN_SLOT_FENCE();
     // slot 1: O1 += V1.P(t-2)            reads: V3            VALU: max over tile 1, group 0
-    st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], pp, st.o[1]);
-    if (TWO) st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], ppl, st.o[1]);
+    st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], pp, st.o[1], st.vsx);
+    if (TWO) st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], ppl, st.o[1], st.vsx);
     v8i fd = LDSF(vprev + (3 << 11));
     mx = max3_raw(mx, sc0[15], sc1[0]);
 #pragma unroll
@@ -280,16 +281,16 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     QATTN_SM_GROUP(true, sc0, 0, mc, 0, pp[0]);
     QATTN_SLOT_FENCE();
     // slot 2: O2 += V2.P(t-2)            reads: Q k-step 0, K(tile 0, k-step 0)      VALU: group 1
-    st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, pp, st.o[2]);
-    if (TWO) st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
+    st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, pp, st.o[2], st.vsx);
+    if (TWO) st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, ppl, st.o[2], st.vsx);
     v8i qf;
     if (QREG) qf = st.qreg[0]; else qf = LDSF(qbuf);
     v8i ka = LDSF(kbuf + (0 << 11));
     QATTN_SM_GROUP(false, sc0, 1, mc, 1, pc[0]);
     QATTN_SLOT_FENCE();
     // slot 3: O3 += V3.P(t-2)            reads: K(tile 1, k-step 0)                  VALU: group 2
-    st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, pp, st.o[3]);
-    if (TWO) st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
+    st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, pp, st.o[3], st.vsx);
+    if (TWO) st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, ppl, st.o[3], st.vsx);
     v8i kb = LDSF(kbuf + (2 << 11));
     QATTN_SM_GROUP(false, sc0, 2, mc, 2, pc[1]);
     QATTN_SLOT_FENCE();
@@ -366,11 +367,11 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
 // going to be repeated in two-term mode anyway: after two more chunks (the votes travel through the sweep's own barrier) all
 // waves drain the ring, stop and return true -- 3 of n chunks wasted instead of all of them.  Chunk 0 stands for the whole
 // key range here; where it does not, the R test at the end of the sweep is still the arbiter.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, typename LoadQ>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, typename LoadQ>
 __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q,
-                                         bool forecast = false, unsigned* vote = nullptr) {
+                                         bool forecast = false, unsigned* vote = nullptr, const unsigned* vx = nullptr) {   // vx (VS): the V chunks' scale bytes in LDS
     constexpr int CH = 64 * D, STAGE = 2 * CH;
     const int hh = lane >> 5;
     const int T = n_wg + 2;  // iterations t = 0 .. n_wg+1 : QK(t), softmax(t-1), PV(t-2)
@@ -445,7 +446,8 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         QATTN2_STAMP(0);
         prep_scores<CAUSAL, TOKEN>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
-        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG>(st, kbuf, vprev, kbuf + CH, qbuf, stage);
+        if constexpr (VS) st.vsx = (int)vx[min(max(t - 2, 0), kVxWords - 1)];   // PV(t - 2) (t = 1: P = 0, any valid scale)
+        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS>(st, kbuf, vprev, kbuf + CH, qbuf, stage);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -526,21 +528,22 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         (void)sync_iter(t);
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         const v8i fc = lds_read_frag(vprev + (2 << 11)), fd = lds_read_frag(vprev + (3 << 11));
+        if constexpr (VS) st.vsx = (int)vx[min(t - 2, kVxWords - 1)];
         // two fully static copies: any run-time choice between st.p[0] and st.p[1] (even by value) ends up as a pointer
         // phi that keeps the P registers in scratch memory
         auto tail = [&](auto par_tag) {
             constexpr int PAR = decltype(par_tag)::value;
             const v8i& pp = st.p[PAR];
             const v8i& ppl = st.pl[TWO ? PAR : 0];
-            st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], pp, st.o[0]);
-            st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], pp, st.o[1]);
-            st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, pp, st.o[2]);
-            st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, pp, st.o[3]);
+            st.o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[0], pp, st.o[0], st.vsx);
+            st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], pp, st.o[1], st.vsx);
+            st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, pp, st.o[2], st.vsx);
+            st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, pp, st.o[3], st.vsx);
             if (TWO) {
-                st.o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[0], ppl, st.o[0]);
-                st.o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(st.vpre[1], ppl, st.o[1]);
-                st.o[2] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fc, ppl, st.o[2]);
-                st.o[3] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(fd, ppl, st.o[3]);
+                st.o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[0], ppl, st.o[0], st.vsx);
+                st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], ppl, st.o[1], st.vsx);
+                st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, ppl, st.o[2], st.vsx);
+                st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, ppl, st.o[3], st.vsx);
             }
             if (BYTE) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
         };
@@ -558,10 +561,11 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
 // caller repeats the block in two-term mode -- or the bit mask of the (at most max_rescue) waves whose 32-row groups
 // rescue_pass then recomputes; the other waves' rows (and the optional LSE) are stored.  0: everything is stored.
 constexpr int kPassRedo = 1 << 30;
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, typename LoadQ>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, typename LoadQ>
 __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
-                                             int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q) {
+                                             int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q,
+                                             const unsigned* vx = nullptr) {
     constexpr int MB = D / 32;
     const int hh = lane >> 5;
     WaveState<D, TWO, BYTE> st;
@@ -587,8 +591,8 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
         }
     };
-    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
-                                                                            !TWO && check_peaked, vote))
+    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
+                                                                                !TWO && check_peaked, vote, vx))
         return kPassRedo;   // forecast: the block is peaked, nothing was stored
 #ifdef QATTN_DEV
     if (p.dbg & 16) {
@@ -705,6 +709,12 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // ds_write -> ds_read with lgkmcnt).  NW words behind the Q area collect the waves' "a row of mine is peaked" votes.
     unsigned char* qbuf = smem + kStagesV2 * STAGE + wave * (KS << 11) + (hh << 10) + (ql << 4);
     unsigned* vote = reinterpret_cast<unsigned*>(smem + kStagesV2 * STAGE + NW * kQPerWave * D);
+    // fused step: the scale bytes of this head's V chunks (block-scaled V; 127 = 2^0 where V has one scale per head), kept in LDS
+    // behind the votes for the PV products of every pass of this block; the sweep's first barrier publishes them
+    unsigned* vx = vote + 16;
+    if (Q16) {
+        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.ssq_stride + i] : 127u;   // (vexp only when nchunks <= kVxWords)
+    }
     float scale_q16 = 1.0f;
     if (Q16) {
         static_assert(!Q16 || !TOKEN, "the fused Q path is head-wise");
@@ -755,8 +765,8 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     };
     // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
     constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
-    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG>(
-        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q);
+    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16>(
+        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx);
 }
 
 // The rescue of a block's flagged 32-row groups as a pass of its own: everything is derived afresh from the (opaque)
@@ -785,7 +795,8 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
         const int fw = __builtin_ctz(rest);
         const unsigned char* qsrc = smem + kStagesV2 * 2 * 64 * D + fw * ((D / 64) << 11) + ((lane >> 5) << 10) + ((lane & 31) << 4);
         rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL, false, true>(p, smem, kg, vg, qb * (NW * kQPerWave) + fw * kQPerWave, wave, lane, bh, kv_head, c,
-                                                               nullptr, [&](int s_) { return lds_read_frag(qsrc + (s_ << 11)); });
+                                                               nullptr, [&](int s_) { return lds_read_frag(qsrc + (s_ << 11)); },
+                                                               Q16 ? reinterpret_cast<const unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D) + 16 : nullptr);
     }
 }
 
@@ -898,7 +909,7 @@ static int launch_attn_v2_one(const AttnParams& pin, hipStream_t st) {
     // one persistent workgroup per CU (a multiple of 8 keeps every workgroup's blocks on one XCD); fewer blocks than CUs: one each
     const int cus = cu_count() & ~7;
     const int grid = (!CAUSAL && p.persistent && cus >= 8 && p.total_blocks > cus) ? cus : p.total_blocks;
-    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64;  // K/V ring + parked Q^T fragments + per-wave vote words
+    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
 #endif
@@ -918,7 +929,7 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
         const int grid = p.B * p.Hq * p.nqb;
-        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64;
+        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords;
         p.n_two = 0; p.peak_r0 = 0.0f; p.total_blocks = grid;
 #define QATTN_ABL_CASE(M)                                                                                          \
         case M: {                                                                                                  \

@@ -175,6 +175,18 @@ __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv
     return r;
 }
 
+// Block-scaled V (fused step, D = 128 head-wise): every 64-key chunk of a kv head is quantised with its own power-of-two
+// scale 2^e, e the smallest exponent with amax / 2^e <= fmax, found inside the quantise pass's own tile -- V needs no abs-max
+// pass -- and applied by the PV products as the E8M0 block scale (byte e + 127) of v_mfma_scale_f32_32x32x64_f8f6f4.
+// From the fp32 bits of the chunk's abs-max, in integer arithmetic so that the test restatement is exact: amax = m 2^k,
+// fmax = 1.75 2^Q (Q = 8 for e4m3, 15 for e5m2)  ->  e = k - Q, one more if m > 1.75; zero, subnormal and non-finite abs-max: e = 0.
+__host__ __device__ inline int vblock_exponent(unsigned amax_bits, int out_fmt) {
+    const int ef = (int)((amax_bits >> 23) & 255u);
+    if (ef == 0 || ef == 255) return 0;
+    const int e = ef - 127 - (out_fmt == QATTN_FMT_E4M3 ? 8 : 15) + ((amax_bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+    return e < -126 ? -126 : e > 126 ? 126 : e;
+}
+
 // the maximum of a head's per-block abs-max words, the same value in every lane
 __device__ inline unsigned max_partials(const unsigned* part, int n, int lane) {
     unsigned m = 0u;
@@ -191,7 +203,7 @@ __device__ inline unsigned max_partials(const unsigned* part, int n, int lane) {
 // `nsplit` partial sums per head (stride kMomentSplits), where quant_moments() finds them (the attention kernel's score-spread
 // estimate, qattn_attn.h predicted_r).
 constexpr int kMomentSplits = 256;   // >= the abs-max pass's blocks per head
-struct QuantMoments { const float* part_q; const float* part_k; const unsigned* amax_q; int nsplit; };
+struct QuantMoments { const float* part_q; const float* part_k; const unsigned* amax_q; const unsigned* vexp; int nsplit; };   // vexp: [B*Hkv][kMomentSplits] E8M0 bytes of the V chunks (block-scaled V)
 inline int amax_splits(int Sq, int Skv, int D) {
     const long vecs = (long)(Sq > Skv ? Sq : Skv) * D / 8;
     const long s = (vecs + 2047) / 2048;   // 8 x 16 B per thread and block
@@ -200,10 +212,10 @@ inline int amax_splits(int Sq, int Skv, int D) {
 inline QuantMoments quant_moments(const unsigned* ws, int B, int Hq, int Hkv, int Sq, int Skv, int D) {
     const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
     const float* s = reinterpret_cast<const float*>(ws + kMomentSplits * (nq + 2 * nk));
-    return QuantMoments{s, s + nq * kMomentSplits, ws, amax_splits(Sq, Skv, D)};
+    return QuantMoments{s, s + nq * kMomentSplits, ws, ws + kMomentSplits * (nq + nk), amax_splits(Sq, Skv, D)};
 }
 int launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                      float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt, int scale_mode,
-                     int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, hipStream_t st);
+                     int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st);
 
 }  // namespace qattn

@@ -209,6 +209,7 @@ struct QuantJob {
 };
 struct QuantJobs {
     QuantJob j[3];
+    unsigned* vexp;       // block-scaled V (else nullptr): [G of v][kMomentSplits] E8M0 bytes, one per 64-key chunk
     int nsplit;           // abs-max-pass blocks per head = valid entries of amax_part / part per head
 };
 
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
     const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
     float scale = 1.0f;
-    if (!token) {
+    if (!token && !(layout == QATTN_LAYOUT_VFRAG && jobs.vexp != nullptr)) {
         scale = make_scale(__uint_as_float(max_partials(jb.amax_part + (long)g * kMomentSplits, jobs.nsplit, tid & 63)), inv_qmax, numerics, IN_FMT);
         if (tile == 0 && tid == 0) jb.scale[g] = scale;
     }
@@ -306,13 +307,52 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     (void)qmax;
     const uint4* xg = jb.x + (long)g * S * VPR;
     const long Sp = (long)((S + 63) / 64) * 64;
+    // block-scaled V (vblock_exponent, qattn_common.h): the tile IS the 64-key chunk; its rows are read once, reduced to the
+    // chunk's abs-max through LDS, and quantised with the power-of-two scale that the attention kernel gets as one byte
+    const bool vblock = layout == QATTN_LAYOUT_VFRAG && jobs.vexp != nullptr;   // uniform over the launch's z slice
+    uint4 held[ITERS];
+    if (vblock) {
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        unsigned m0 = 0;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int vec = it * 256 + tid;
+            const int row = row0 + vec / VPR;
+            held[it] = make_uint4(0, 0, 0, 0);
+            if (row < S) held[it] = xg[(long)row * VPR + vec % VPR];
+            const unsigned w[4] = {held[it].x & 0x7fff7fffu, held[it].y & 0x7fff7fffu, held[it].z & 0x7fff7fffu, held[it].w & 0x7fff7fffu};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                u16x2 a, b;
+                __builtin_memcpy(&a, &w[i], 4); __builtin_memcpy(&b, &m0, 4);
+                b = __builtin_elementwise_max(a, b);
+                __builtin_memcpy(&m0, &b, 4);
+            }
+        }
+        unsigned m = max(m0 & 0xffffu, m0 >> 16);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+        unsigned* red = reinterpret_cast<unsigned*>(img);
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        __syncthreads();   // (img is written below)
+        const int e = vblock_exponent(__float_as_uint(load16f<IN_FMT>((unsigned short)m)), OUT_FMT);
+        scale = __uint_as_float((unsigned)(e + 127) << 23);
+        rinv = __uint_as_float((unsigned)(127 - e) << 23);
+        if (tid == 0) {
+            jobs.vexp[(long)g * kMomentSplits + tile] = (unsigned)(e + 127);
+            if (tile == 0) jb.scale[g] = 1.0f;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int vec = it * 256 + tid;
         const int r = vec / VPR, dv = vec % VPR;
         const int row = row0 + r;
         uint4 raw = make_uint4(0, 0, 0, 0);
-        if (row < S) raw = xg[(long)row * VPR + dv];
+        if (vblock) raw = held[it];
+        else if (row < S) raw = xg[(long)row * VPR + dv];
         unsigned short e[8];
         __builtin_memcpy(e, &raw, 16);
         float f[8];
@@ -818,18 +858,20 @@ extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, 
     const size_t need = qattn_quant_qkv_workspace_bytes(B, Hq, Hkv);
     if (!workspace || workspace_bytes < need) return QATTN_ERR_WORKSPACE;
     return qattn::launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, out_fmt, scale_mode,
-                                   numerics, (unsigned*)workspace, false, false, (hipStream_t)stream);
+                                   numerics, (unsigned*)workspace, false, false, false, (hipStream_t)stream);
 }
 
 int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                             float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt,
-                            int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, hipStream_t st) {
+                            int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st) {
     const int tok = scale_mode == QATTN_SCALE_TOKEN;
     const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
     float* part = reinterpret_cast<float*>(ws + kMomentSplits * (nq + 2 * nk));   // q heads then k heads
     const bool moments = !tok && want_moments;
     QuantJobs jobs;
     jobs.nsplit = amax_splits(Sq, Skv, D);
+    const bool vblock = v_block && !tok && (Skv + 63) / 64 <= kMomentSplits;   // V's 256 words per head hold the chunks' scale bytes instead of abs-max words
+    jobs.vexp = vblock ? ws + kMomentSplits * (nq + nk) : nullptr;
     jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok,
                          moments ? part : nullptr};
     jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + kMomentSplits * nq, B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
@@ -855,7 +897,7 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
 #else
         const bool oneread = false;
 #endif
-        dim3 grid(splits, oneread ? B * Hq : Gmax, oneread ? 1 : 3), block(256);
+        dim3 grid(splits, oneread ? B * Hq : Gmax, oneread ? 1 : vblock ? 2 : 3), block(256);   // (block-scaled V: no abs-max pass over v)
         if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, splits, 0);
         else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, splits, 0);
 #ifdef QATTN_DEV

@@ -44,9 +44,20 @@ def unpack_frag(buf: np.ndarray, layout: int, B: int, H: int, S: int, D: int) ->
     return x[..., off].reshape(B, H, Sp, D)
 
 
+def fused_step_uses_block_v(D, scaling, dtype, Skv) -> bool:
+    """Mirror of qattn_fp8_quant_attention_forward's choice (csrc/qattn_api.hip): block-scaled V where the hand-scheduled D = 128
+    head-wise kernel quantises bf16 Q itself and a head has at most 256 chunks; everywhere else V has one scale per head."""
+    return D == 128 and scaling in ("head", "head-wise") and dtype == torch.bfloat16 and (Skv + 63) // 64 <= 256
+
+
 def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfloat16, scaling="head", causal=False,
-                        sm_scale=0.0, return_lse=False):
-    """O3 of SURVEY.md §8c: fp64 SDPA on the same quantised q, k AND the build's quantised v."""
+                        sm_scale=0.0, return_lse=False, v_block=False):
+    """O3 of SURVEY.md §8c: fp64 SDPA on the same quantised q, k AND the build's quantised v (v_block: the fused step's
+    block-scaled V, oracle.quantize_v_block; else one scale per head)."""
+    if v_block:
+        _, _, vdq = oracle.quantize_v_block(v16b, fmt16(v_dtype), FMT[fp8])
+        return oracle.attention_forward(q8b, k8b, vdq, FMT[fp8], FMT[fp8], oracle.FMT_BF16, sq, sk, None, scale_mode=scaling,
+                                        causal=causal, sm_scale=sm_scale, return_lse=return_lse)
     v8, sv = oracle.quantize_fp8(v16b, fmt16(v_dtype), "head", FMT[fp8], "compiled")
     return oracle.attention_forward(q8b, k8b, v8, FMT[fp8], FMT[fp8], FMT[fp8], sq, sk, sv, scale_mode=scaling,
                                     causal=causal, sm_scale=sm_scale, return_lse=return_lse)

@@ -14,7 +14,7 @@ import oracle
 import quantumattention_amd as qa
 from quantumattention_amd import _native
 from tests.conftest import GOLDEN, golden_files
-from tests.gpu_utils import (FMT, TDT, bits16, bits8, err_stats, fmt16, from_bits16, oracle_for_fp8_path, out_to_f32)
+from tests.gpu_utils import (FMT, TDT, bits16, bits8, err_stats, fmt16, from_bits16, fused_step_uses_block_v, oracle_for_fp8_path, out_to_f32)
 
 pytestmark = pytest.mark.gpu
 
@@ -102,20 +102,26 @@ def test_fused_path_from_16bit_inputs(case):
     q8, sq = oracle.quantize_fp8(bits16(q), fmt16(dtype), m, FMT[fp8])
     k8, sk = oracle.quantize_fp8(bits16(k), fmt16(dtype), m, FMT[fp8])
     ref, ref_lse = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal,
-                                       return_lse=True)
+                                       return_lse=True)       # V with one scale per head: the separate C calls below
+    vb = fused_step_uses_block_v(D, scaling, dtype, Skv)      # the fused step quantises V per 64-key chunk there
+    ref_fused = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal, v_block=True) if vb else ref
     out = torch.ops.quantumattention_amd.fp8_quant_attention_forward(q.cuda(), k.cuda(), v.cuda(), causal, scaling, fp8)
     got = out_to_f32(out)
     assert np.isfinite(got).all()
-    mx, rmse = err_stats(got, ref)
-    assert mx < tol_for(ref), (mx, rmse)
-    assert rmse < 2e-3 * max(1.0, float(np.abs(ref).max())), (mx, rmse)
+    mx, rmse = err_stats(got, ref_fused)
+    assert mx < tol_for(ref_fused), (mx, rmse)
+    assert rmse < 2e-3 * max(1.0, float(np.abs(ref_fused).max())), (mx, rmse)
     # optional LSE output (the vector the reference defines but disables, tk/attention.py:333-346)
     qg8, sqg = _native.quant_fp8(q.cuda(), scaling=scaling, fp8_dtype=TDT[fp8])
     kf, skg = _native.quant_fp8(k.cuda(), scaling=scaling, fp8_dtype=TDT[fp8], layout=_native.LAYOUT_KFRAG)
     vf, svg = _native.quant_fp8(v.cuda(), scaling="head-wise", fp8_dtype=TDT[fp8], layout=_native.LAYOUT_VFRAG)
     out2 = _native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype,
                                          is_causal=causal, scaling=scaling)
-    assert torch.equal(out2, out), "the op and the direct C-ABI sequence must agree bit for bit"
+    if vb:   # different V formats: each against its own oracle
+        mx2, rmse2 = err_stats(out_to_f32(out2), ref)
+        assert mx2 < tol_for(ref) and rmse2 < 2e-3 * max(1.0, float(np.abs(ref).max())), (mx2, rmse2)
+    else:
+        assert torch.equal(out2, out), "the op and the direct C-ABI sequence must agree bit for bit"
     # asking for the LSE selects the exact-exponential path (the fast path's row sum is of the quantised P)
     out3, lse = _native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype,
                                               is_causal=causal, scaling=scaling, return_lse=True)
@@ -169,7 +175,7 @@ def test_rescale_branch_forced_by_a_spiked_key():
     for causal in (False, True):
         q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
         k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
-        ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal)
+        ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal, v_block=True)   # fp8_attn_func = the fused step
         out = qa.fp8_attn_func(q.cuda(), k.cuda(), v.cuda(), is_causal=causal)
         mx, rmse = err_stats(out_to_f32(out), ref)
         assert mx < tol_for(ref), (causal, mx, rmse)
@@ -194,7 +200,7 @@ def test_full_size_properties_B4_H32_S4096_D128(causal):
         qs, ks, vs = q[b:b + 1, h:h + 1].cpu(), k[b:b + 1, h:h + 1].cpu(), v[b:b + 1, h:h + 1].cpu()
         q8, sq = oracle.quantize_fp8(bits16(qs), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
         k8, sk = oracle.quantize_fp8(bits16(ks), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
-        ref = oracle_for_fp8_path(q8, k8, bits16(vs), sq, sk, causal=causal)[0, 0, rows]
+        ref = oracle_for_fp8_path(q8, k8, bits16(vs), sq, sk, causal=causal, v_block=True)[0, 0, rows]
         got = out_to_f32(out[b, h, rows])
         mx, rmse = err_stats(got, ref)
         assert mx < TOL, (b, h, mx, rmse)
@@ -240,7 +246,7 @@ def test_full_size_properties_config5_shape_S16384_H40_e5m2_causal():
     q8, sq = oracle.quantize_fp8(bits16(qs), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
     k8, sk = oracle.quantize_fp8(bits16(ks), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
     top = 1536   # top-left causal alignment: query rows [0, top) against the full K / V (V quantised with the head's scale)
-    ref_top = oracle_for_fp8_path(q8[:, :, :top], k8, bits16(vs), sq, sk, fp8="e5m2", causal=True)
+    ref_top = oracle_for_fp8_path(q8[:, :, :top], k8, bits16(vs), sq, sk, fp8="e5m2", causal=True, v_block=True)
     mx, rmse = err_stats(out_to_f32(out[0, h, :top]), ref_top[0, 0])
     assert mx < tol_for(ref_top) and rmse < 3e-3, (mx, rmse)
     # last rows see every key: non-causal oracle rows == causal rows for the final row only; use Sq != Skv non-causal instead

@@ -26,7 +26,7 @@ def _oracle(q, k, v, causal, fp8="e4m3"):
     fmt = oracle.FMT_E4M3 if fp8 == "e4m3" else oracle.FMT_E5M2
     q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", fmt)
     k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", fmt)
-    return oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, causal=causal)
+    return oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, causal=causal, v_block=q.shape[-1] == 128)   # _run is the fused step
 
 
 def _run(q, k, v, causal, precision, fp8="e4m3"):
@@ -148,7 +148,7 @@ def test_gqa_with_one_wide_kv_group():
     q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
     k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
     for causal in (False, True):
-        ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8="e4m3", causal=causal)
+        ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8="e4m3", causal=causal, v_block=True)
         got = _run(q, k, v, causal, "auto")
         assert np.isfinite(got).all()
         assert err_stats(got, ref)[0] < TOL, (causal, err_stats(got, ref))
@@ -210,7 +210,7 @@ def test_config5_at_its_stated_size_B4_H40_S16384_e5m2_causal():
     qs, ks, vs = q[b:b + 1, h:h + 1].cpu(), k[b:b + 1, h:h + 1].cpu(), v[b:b + 1, h:h + 1].cpu()
     q8, sq = oracle.quantize_fp8(bits16(qs), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
     k8, sk = oracle.quantize_fp8(bits16(ks), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
-    ref_top = oracle_for_fp8_path(q8[:, :, :top], k8, bits16(vs), sq, sk, fp8="e5m2", causal=True)
+    ref_top = oracle_for_fp8_path(q8[:, :, :top], k8, bits16(vs), sq, sk, fp8="e5m2", causal=True, v_block=True)
     mx, rmse = err_stats(out_to_f32(out[b, h, :top]), ref_top[0, 0])
     assert mx < TOL * max(1.0, float(np.abs(ref_top).max()) / 2.0) and rmse < 3e-3, (mx, rmse)   # |O| > 2 only on the first rows
     tail = slice(S - 256, S)

@@ -138,3 +138,42 @@ def test_quant_fast_path_bit_exact_on_adversarial_bit_patterns(scaling, numerics
     nan_ref = (ref8 & 0x7f) == 0x7f
     np.testing.assert_array_equal((got & 0x7f) == 0x7f, nan_ref)     # NaN bytes in the same places (sign of NaN is free)
     np.testing.assert_array_equal(got[~nan_ref], ref8[~nan_ref])
+
+
+@pytest.mark.parametrize("fp8", ["e4m3", "e5m2"])
+def test_fused_step_block_scaled_v_is_bit_exact(fp8):
+    """The fused step (D = 128, head-wise, bf16) quantises V with one power-of-two scale per 64-key chunk inside its quantise pass
+    (no abs-max pass over V): payload (VFRAG) and scale bytes against oracle.quantize_v_block, on ragged S, with a zero chunk, a
+    huge chunk, a tiny chunk and an inf."""
+    from quantumattention_amd._native import LAYOUT_KFRAG, LAYOUT_VFRAG, SCALE_HEAD, PRECISION, fmt_of, _stream
+    torch.manual_seed(3)
+    B, H, S, D = 2, 3, 1000, 128
+    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    v[0, 0, 64:128] = 0
+    v[0, 1, 128:192] *= 3.0e4
+    v[0, 2, 192:256] *= 1.0e-6
+    v[1, 0, 300, 5] = float("inf")
+    L = _native.lib()
+    dev = q.device
+    out = torch.empty_like(q)
+    q8 = torch.empty((B, H, S, D), dtype=torch.uint8, device=dev)
+    kf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, H, S, D),), dtype=torch.uint8, device=dev)
+    vf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, H, S, D),), dtype=torch.uint8, device=dev)
+    sq, sk, sv = (torch.empty((B, H), dtype=torch.float32, device=dev) for _ in range(3))
+    ws_bytes = L.qattn_fp8_quant_attention_workspace_bytes(B, H, H, S)
+    ws = torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev)
+    rc = L.qattn_fp8_quant_attention_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(),
+                                             kf.data_ptr(), vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, H, H, S, S, D,
+                                             FMT[fp8], SCALE_HEAD, 0, 0, 0.0, PRECISION["auto"], ws.data_ptr(), ws_bytes, _stream(q))
+    torch.cuda.synchronize()
+    assert rc == 0
+    ref8, refe, _ = oracle.quantize_v_block(bits16(v), oracle.FMT_BF16, FMT[fp8])
+    nch = (S + 63) // 64
+    n = B * H
+    words = ws.view(torch.int32).cpu().numpy()
+    got_e = words[256 * 2 * n: 256 * 3 * n].reshape(B, H, 256)[:, :, :nch]      # V's 256 words per head, behind q's and k's
+    np.testing.assert_array_equal(got_e, refe.astype(np.int32))
+    got8 = unpack_frag(bits8(vf), LAYOUT_VFRAG, B, H, S, D)[:, :, :S]
+    nan_ref = (ref8 & 0x7f) == 0x7f if fp8 == "e4m3" else (ref8 & 0x7f) > 0x7c
+    np.testing.assert_array_equal(got8[~nan_ref], ref8[~nan_ref])
+    np.testing.assert_array_equal(sv.cpu().numpy(), np.ones((B, H), np.float32))
