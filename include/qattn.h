@@ -170,7 +170,11 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
  * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
- * and one write of Q.  Results are bit-identical to the separate calls, with one documented exception: under
+ * and one write of Q.  There (and for Skv <= 16384) V is also quantised differently from qattn_quant_qkv_fp8: one power-of-two
+ * scale per 64-key chunk, found inside the quantise pass (no abs-max pass over V) and applied by the kernel's PV products as
+ * the MFMA's E8M0 block scale; v8 then holds those payloads, scale_v is written as 1.0 and the chunk scales live in the
+ * workspace (oracle restatement: oracle.quantize_v_block).  Everywhere else results are bit-identical to the separate
+ * calls, with one more documented exception: under
  * QATTN_PRECISION_AUTO (head-wise, D = 128) the pre-pass also hands the attention kernel every head's sum of squares, and a
  * head whose predicted score variance is >= 1.5 starts in two-term mode (what QATTN_PRECISION_ACCURATE computes for it) instead
  * of being swept once with one-term P first; heads below that -- N(0,1)-like data -- take the same decisions as the separate calls.
