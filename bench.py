@@ -117,7 +117,7 @@ def kernel_label(D, fp8, causal, fused_q):
     """The kernel the dispatch in qattn_api.hip / qattn_attn_v2.hip / qattn_attn_v4.hip selects for a head-wise call."""
     if D == 128:
         return (f"qattn::attn_fwd_kernel_v2<D=128, 8 waves, {fp8}, {'causal' if causal else 'full'}, head-wise, byte-exp"
-                f"{', Q quantised in-kernel' if fused_q else ''}> (fused QK^T / softmax / PV; one launch per batch group, all query blocks)")
+                f"{', Q quantised in-kernel, block-scaled V' if fused_q else ''}> (fused QK^T / softmax / PV; one launch, all query blocks)")
     return f"qattn::attn_fwd_kernel_v4<D={D}, {fp8}, {'causal' if causal else 'full'}, head-wise, byte-exp> (+ two-term launch for early causal rows)"
 
 
