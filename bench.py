@@ -19,6 +19,8 @@ The JSON line also carries
                   dense fp8 MFMA peak;
   cpu_baseline -- the reference's CPU path (torch port of ops.py:64-95, oracle/torch_ref.py) timed on the host cores
                   on a bounded sample of the same workload;
+  quant_prepass_ms / quant_prepass_in_step_ms -- the separate qattn_quant_qkv_fp8 call, and the pre-pass inside the step (step
+                  minus attention), each against 603.98 MB of algorithmic bytes at C2;
   sustained_ms_per_step, c3_*, c5_* -- a >= 2 s back-to-back run and the causal / long-context configs (N=1 only).
 Timing protocol: --settle seconds (default 0.3) of untimed steps bring the idle GPU (sclk ~100 MHz) to its sustained,
 power-capped state (tools/time_ramp.py: the first 20 steps after idle run 16 % slower than the next thousands), then the W
@@ -300,7 +302,12 @@ def run_rank(args):
         quant_alg_bytes = 3 * (2 + 1) * B * H * S * D   # read 2 B + write 1 B per element of q, k, v
         line.update({
             "attn_kernel_ms": attn_ms, "attn_kernel_isolated_ms": attn_isolated_ms, "quant_prepass_ms": quant_ms,
-            "quant_prepass_algorithmic_TBps": quant_alg_bytes / (quant_ms * 1e-3) / 1e12, "graph_replay_ms_per_step": graph_ms,
+            "quant_prepass_algorithmic_TBps": quant_alg_bytes / (quant_ms * 1e-3) / 1e12,
+            # the pre-pass AS IT RUNS IN THE STEP (Q quantised by the attention kernel, V block-scaled without an abs-max pass
+            # where that kernel applies): step minus the in-step attention launches, against the same algorithmic bytes
+            "quant_prepass_in_step_ms": line["ms_per_step"] - attn_ms,
+            "quant_prepass_in_step_algorithmic_TBps": quant_alg_bytes / ((line["ms_per_step"] - attn_ms) * 1e-3) / 1e12 if line["ms_per_step"] > attn_ms else None,
+            "graph_replay_ms_per_step": graph_ms,
             "roofline": {"kernel": kernel_label(D, args.fp8, args.causal, D == 128),
                          "bound": "mfma", "achieved": achieved, "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP8_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source},
