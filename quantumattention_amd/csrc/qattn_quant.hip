@@ -893,7 +893,7 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
         // (experiment: the one-read team kernel for head-wise K and V; one workgroup per CU, whole teams per XCD)
         const int NS = (Skv + kSliceBytes / (D * 2) - 1) / (kSliceBytes / (D * 2));
         const int tpx = NS >= 1 ? 32 / NS : 0;
-        const bool oneread = !tok && tpx >= 1 && D <= 128 && one_read_enabled();
+        const bool oneread = !tok && tpx >= 1 && D <= 128 && !vblock && one_read_enabled();   // (the team kernel scales V per head)
 #else
         const bool oneread = false;
 #endif
