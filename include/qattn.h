@@ -180,6 +180,9 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * of being swept once with one-term P first; heads below that -- N(0,1)-like data -- take the same decisions as the separate calls.
  */
 size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int Hkv, int Sq);
+/* The exponent e of the block-scaled V's chunk scale 2^e, from the fp32 bits of the chunk's abs-max (host function, the same
+ * integer rule the quantise pass applies on the device; out_fmt: QATTN_FMT_E4M3 / QATTN_FMT_E5M2).  The E8M0 byte is e + 127. */
+int qattn_vblock_exponent(unsigned amax_bits, int out_fmt);
 int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8, void* k8,
                                       void* v8, float* scale_q, float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq,
                                       int Skv, int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,

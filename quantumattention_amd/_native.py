@@ -30,7 +30,7 @@ EXPORTS = (
     "qattn_pack_fp8", "qattn_fp8_attention_forward",
     "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16", "qattn_fp8_quant_attention_forward",
     "qattn_attention_workspace_bytes", "qattn_lse_row_stride", "qattn_fp8_quant_attention_workspace_bytes",
-    "qattn_profile_attention", "qattn_last_attention_ms",
+    "qattn_profile_attention", "qattn_last_attention_ms", "qattn_vblock_exponent",
 )
 
 _lib = None
@@ -52,6 +52,8 @@ def lib() -> ctypes.CDLL:
     L.qattn_strerror.restype = ctypes.c_char_p
     L.qattn_strerror.argtypes = [i]
     L.qattn_check_device.restype = i
+    L.qattn_vblock_exponent.restype = i
+    L.qattn_vblock_exponent.argtypes = [ctypes.c_uint, i]
     L.qattn_fp8_tensor_bytes.restype = sz
     L.qattn_fp8_tensor_bytes.argtypes = [i, i, i, i, i]
     L.qattn_quant_workspace_bytes.restype = sz

@@ -803,6 +803,8 @@ extern "C" int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, i
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
 
+extern "C" int qattn_vblock_exponent(unsigned amax_bits, int out_fmt) { return qattn::vblock_exponent(amax_bits, out_fmt); }
+
 extern "C" size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0) return 0;
     // [per-block abs-max bits of q, k, v | per-block sums of squares of q, k]: kMomentSplits words per head each; nothing to zero

@@ -199,3 +199,26 @@ def test_force_eager_fallback_runs_the_ops_eager_definition():
         with qa.config.patch({"attention.fp8_format": "e5m2"}):
             q8, _ = qa.dynamically_quantize_fp8(q, reduction_dim=[2, 3])
             assert q8.dtype == torch.float8_e5m2   # the eager fallback follows config.attention.fp8_format
+
+
+def test_vblock_exponent_matches_the_oracle_restatement():
+    """The integer rule for the block-scaled V's chunk scale (csrc/qattn_common.h vblock_exponent, exported as a host function)
+    against oracle.quantize_v_block on chunks whose abs-max is a chosen bf16 value: around the 1.75 x 2^k boundaries, tiny, huge,
+    zero, inf, NaN."""
+    import numpy as np
+    import oracle
+    L = _native.lib()
+    vals = [0.0, 1e-30, 3.0e-5, 0.4375, 0.4394, 1.0, 1.75, 1.7578125, 3.5, 3.515625, 447.0, 448.0, 450.0, 57344.0, 57600.0, 1e10, 3e38,
+            float("inf"), float("nan")]
+    for fmt, name in ((oracle.FMT_E4M3, "e4m3"), (oracle.FMT_E5M2, "e5m2")):
+        x = np.zeros((1, len(vals), 64, 64), np.float32)
+        x[0, :, 7, 3] = np.array(vals, np.float32)
+        bits = oracle.f32_to_bf16_bits(x)
+        amax = oracle.bf16_bits_to_f32(bits)[0, :, 7, 3]
+        _, e8, _ = oracle.quantize_v_block(bits, oracle.FMT_BF16, fmt)
+        for i, a in enumerate(amax):
+            got = L.qattn_vblock_exponent(int(np.float32(a).view(np.uint32)), fmt)
+            assert got + 127 == int(e8[0, i, 0]), (name, vals[i], got, int(e8[0, i, 0]))
+            if np.isfinite(a) and a >= 1.1754944e-38:   # the smallest power of two that brings the chunk inside the format's range
+                fmax = 448.0 if fmt == oracle.FMT_E4M3 else 57344.0
+                assert a / 2.0 ** got <= fmax and (got == -126 or a / 2.0 ** (got - 1) > fmax), (name, vals[i], got)
