@@ -147,8 +147,9 @@ def quantize_v_block(v_bits: np.ndarray, in_fmt: int, fmt: int = FMT_E4M3):
 
 def attention_forward(q, k, v, q_fmt, k_fmt, v_fmt, scale_q=None, scale_k=None, scale_v=None,
                       scale_mode: str = "head", causal: bool = False, sm_scale: float = 0.0,
-                      return_lse: bool = False):
+                      return_lse: bool = False, q_offset: int = 0):
     """fp64-evaluated SDPA on the given (quantised) inputs; restates ops.py:64-95 / :17-29.
+    q_offset (causal only): the query rows are rows q_offset .. of a longer causal problem (key j <= q_offset + i).
 
     q/k/v: numpy arrays of raw bits (uint8 for fp8 formats, uint16 for bf16/fp16), [B,H,S,D]."""
     dt = lambda fmt: np.uint8 if fmt in (FMT_E4M3, FMT_E5M2) else np.uint16
@@ -160,7 +161,7 @@ def attention_forward(q, k, v, q_fmt, k_fmt, v_fmt, scale_q=None, scale_k=None, 
     out = np.empty((B, Hq, Sq, D), np.float32)
     lse = np.empty((B, Hq, Sq), np.float32) if return_lse else None
     rc = lib().qo_attention_forward(_ptr(q), _ptr(k), _ptr(v), q_fmt, k_fmt, v_fmt, _ptr(sq), _ptr(sk), _ptr(sv),
-                                    {"head": 0, "token": 1}[scale_mode], B, Hq, Hkv, Sq, Skv, D, int(causal),
+                                    {"head": 0, "token": 1}[scale_mode], B, Hq, Hkv, Sq, Skv, D, (1 + int(q_offset)) if causal else 0,
                                     float(sm_scale), _ptr(out), _ptr(lse))
     if rc != 0:
         raise RuntimeError(f"qo_attention_forward failed: {rc}")

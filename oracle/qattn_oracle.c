@@ -180,7 +180,9 @@ int qo_quantize_fp8(const uint16_t* x, int in_dtype, long groups, long inner, in
 /*   q,k: [B,Hq|Hkv,S,D] in q_fmt/k_fmt (fp8 byte or 16-bit); v: [B,Hkv,Skv,D] in v_fmt.             */
 /*   scale_q/scale_k: NULL, or fp32 [B,H] (scale_mode 0, head-wise) / [B,H,S] (scale_mode 1).        */
 /*   scale_v: NULL or fp32 [B,Hkv] (build extension: quantised V).                                   */
-/*   sm_scale <= 0 -> 1/sqrt(D) (aten default).  causal: keep key j <= query i (aten top-left).       */
+/*   sm_scale <= 0 -> 1/sqrt(D) (aten default).  causal = 1: keep key j <= query i (aten top-left);  */
+/*   causal = 1 + r0: the Sq rows are rows r0 .. r0+Sq-1 of a longer causal problem (key j <= r0 + i) */
+/*   -- lets a test check a band of rows of a long sequence without attending the rows before it.     */
 /*   out: fp32 [B,Hq,Sq,D]; lse (optional): fp32 [B,Hq,Sq] natural-log-sum-exp of the scaled scores.  */
 /* ----------------------------------------------------------------------------------------------- */
 static void dequant_rows(const void* src, int fmt, long n, double mul, float* dst) {
@@ -232,7 +234,7 @@ int qo_attention_forward(const void* q, const void* k, const void* v, int q_fmt,
                     double sq = 1.0;
                     if (scale_q) sq = scale_mode == 1 ? (double)scale_q[((long)b * Hq + h) * Sq + i] : (double)scale_q[(long)b * Hq + h];
                     dequant_rows((const char*)q + q_off * elt_size(q_fmt), q_fmt, D, 1.0, qf);
-                    const int jmax = causal ? (i + 1 < Skv ? i + 1 : Skv) : Skv;
+                    const int jmax = causal > 0 ? ((long)i + causal < (long)Skv ? i + causal : Skv) : Skv;
                     double m = -INFINITY;
                     for (int j = 0; j < jmax; j++) {
                         const float* kr = kf + (long)j * D;

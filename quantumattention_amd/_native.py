@@ -102,6 +102,11 @@ def _scale_mode(scaling: str) -> int:
     return SCALE_HEAD if scaling == "head-wise" else SCALE_TOKEN
 
 
+def _precision(name) -> int:
+    _require(name in PRECISION, f"Unsupported precision: {name!r} (expected one of {sorted(PRECISION)})")
+    return PRECISION[name]
+
+
 def _check_qkv(q, k, v):
     """q [B,Hq,Sq,D], k / v [B,Hkv,Skv,D] on one device with one 16-bit dtype (tk/attention.py:362-400)."""
     _require(q.is_cuda and q.dim() == 4 and k.dim() == 4 and v.dim() == 4, "query, key and value must be 4-D device tensors")
@@ -238,7 +243,7 @@ def fp8_attention_forward(q8: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.
             scale_q.contiguous().data_ptr(), scale_k.contiguous().data_ptr(),
             _ptr(scale_v.contiguous() if scale_v is not None else None),
             B, Hq, Hkv, Sq, Skv, D, fmt_of(q8.dtype), fmt_of(q8.dtype), fmt_of(out_dtype), mode, int(is_causal),
-            float(sm_scale), PRECISION[precision], lse_layout, ws.data_ptr(), ws_bytes, _stream(q8))
+            float(sm_scale), _precision(precision), lse_layout, ws.data_ptr(), ws_bytes, _stream(q8))
     _check(rc, "qattn_fp8_attention_forward")
     if return_lse:
         return out, lse[..., :Sq]  # [B,Hq,Sq] view; strides (Hq*ld, ld, 1) with ld = the padded row for LSE_REFERENCE
@@ -301,6 +306,6 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         rc = L.qattn_fp8_quant_attention_forward(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
             vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
-            NUMERICS[numerics], int(is_causal), float(sm_scale), PRECISION[precision], ws.data_ptr(), ws_bytes, _stream(q))
+            NUMERICS[numerics], int(is_causal), float(sm_scale), _precision(precision), ws.data_ptr(), ws_bytes, _stream(q))
     _check(rc, "qattn_fp8_quant_attention_forward")
     return out

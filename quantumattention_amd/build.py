@@ -13,12 +13,15 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
+# `-save-temps` output (79 MB of .s / .bc / .hipi for tests/test_kernel_resources.py and tools/kernel_resources.py) lives in a
+# directory of its own that neither git nor gpurun ships (.gitignore, .gpurunignore); the objects of the shipped library do not
+BUILD_TEMPS = os.path.join(HERE, "_build_temps")
 LIB = os.path.join(HERE, "libqattn_hip.so")
 SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip"]
 # (source, extra flags, object name): the two big kernel files are compiled once per operand format / head dimension so that
 # the build runs in parallel (the longest single translation unit sets the wall time)
 # (a unit with a define is compiled through a two-line wrapper file named after the unit, so that -save-temps leaves one .s
-# per unit for tests/test_kernel_resources.py)
+# per unit)
 UNITS = [
     ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0"], "qattn_attn_v2_e4m3"),
     ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1"], "qattn_attn_v2_e5m2"),
@@ -51,7 +54,9 @@ def _stale(out, deps):
 
 
 def build(force: bool = False, save_temps: bool = False, verbose: bool = False, dev: bool = False) -> str:
-    build_dir = BUILD + ("_dev" if dev else "")
+    """Compile what is stale and link the library; returns its path.  save_temps: compile every unit with -save-temps into
+    BUILD_TEMPS instead (same flags, same code; the library is left alone) and return that directory."""
+    build_dir = BUILD_TEMPS if save_temps else BUILD + ("_dev" if dev else "")
     lib = LIB.replace(".so", "_dev.so") if dev else LIB
     os.makedirs(build_dir, exist_ok=True)
     hipcc = _hipcc()
@@ -79,6 +84,8 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
         subprocess.check_call(cmd, cwd=build_dir)
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
+    if save_temps:
+        return build_dir
     if force or jobs or _stale(lib, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)
     return lib

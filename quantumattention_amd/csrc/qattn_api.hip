@@ -102,7 +102,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.nqb = ceil_div(a.Sq, kQPerWG);
     p.nchunks = ceil_div(a.Skv, 64);
     p.out_fmt = a.out_fmt;
-    p.xcd_remap = ((a.B * a.Hq) % 8 == 0) ? 1 : 0;
+    p.xcd_remap = ((a.B * a.Hq) % 8 == 0 && xcd_count() == 8) ? 1 : 0;   // (the maps of qattn_attn.h are written for 8 XCDs)
     // causal: heads taken in groups whose K + V (2 Skv D bytes of fp8 per head) stay within half of an XCD's 4 MiB L2 -- with
     // 4 heads at S = 4096 (4 MiB) the PMC passes counted 1.3x the algorithmic HBM bytes, at S = 16384 (16 MiB) 2.4x
     p.causal_group = 1;
@@ -113,6 +113,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.precision = a.precision;
     p.two_term_keys = kTwoTermKeys;
     p.peak_r0 = a.precision == QATTN_PRECISION_AUTO ? kPeakR0 : 0.0f;
+    p.peak_neff = a.precision == QATTN_PRECISION_AUTO ? kPeakNeff : 0.0f;
     p.max_rescue = kMaxRescueWaves;
     p.persistent = 1;
     p.no_forecast = 0;
@@ -131,6 +132,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.exact_exp = e.exact_exp;
     p.two_term_keys = e.two_term_keys;
     if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = e.peak_r0;
+    if (a.precision == QATTN_PRECISION_AUTO && getenv("QATTN_PEAK_NEFF")) p.peak_neff = (float)atof(getenv("QATTN_PEAK_NEFF"));
     if (getenv("QATTN_MAX_RESCUE")) p.max_rescue = atoi(getenv("QATTN_MAX_RESCUE"));
     if (getenv("QATTN_PERSISTENT")) p.persistent = atoi(getenv("QATTN_PERSISTENT"));
     if (getenv("QATTN_NO_FORECAST")) p.no_forecast = atoi(getenv("QATTN_NO_FORECAST"));

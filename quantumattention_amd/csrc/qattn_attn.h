@@ -17,6 +17,14 @@ constexpr int kTwoTermKeys = 1024;           // query blocks that see fewer keys
 // One-term rows are re-done with two-term P when R = l / p_max (the inverse of the row's largest softmax weight) ends below
 // this: the error a single e4m3-rounded weight w contributes is about w * 2^-4 * |v - O|  
 constexpr float kPeakR0 = 24.0f;
+// ... and when its effective key count N_eff = l^2 / sum P'^2 ends below this.  R bounds the LARGEST weight; K similar weights
+// that carry a row have R ~ K and a one-term error ~ eps_rms |v - O| / sqrt(K): 0.026 at K = 40, 0.017 at K = 100, 0.0125 at
+// K = 160, 0.010 at K = 256 (tools/sim_heavy.py; 2^-6 = 0.0156).  N(0,1) rows sit at n / e: 1500 at n = 4096, 390 at 1024,
+// where a row with R >= 24 is never below 192 (3e-4 of the rows at n = 1024).
+constexpr float kPeakNeff = 192.0f;
+// the e4m3 byte of P' read as e5m2 is 0.444 .. 0.5 of P'^2 over the eight mantissa values (mean 0.480); the MFMA that sums
+// it stands for kNeffByteRatio * sum P'^2
+constexpr float kNeffByteRatio = 0.472f;
 // Which blocks START in two-term mode: those whose rows are predicted to end below kPeakR0 anyway.  For scores ~ N(0, var)
 // over n keys the row sum is about n exp(var / 2) and the largest term sits about z standard deviations out, so the smallest
 // R in a block is about n exp(var / 2 - z sqrt(var)); z (AttnParams::peak_z = 1/2 + ln(kTwoTermKeys / kPeakR0) = 4.25) makes
@@ -66,6 +74,7 @@ struct AttnParams {
     int two_term_keys;  // kTwoTermKeys (a development switch can change it)
     int n_two;       // leading query blocks per head that start in two-term mode (set by the launcher)
     float peak_r0;
+    float peak_neff;             // kPeakNeff (0 with peak_r0 = 0)
     const float* ssq_q;          // fused step, head-wise: partial sums of squares of every q head [B*Hq][ssq_stride] and k
     const float* ssq_k;          //   head [B*Hkv][ssq_stride], ssq_n of them valid per head (else nullptr)
     int ssq_n, ssq_stride;
@@ -167,6 +176,24 @@ __device__ inline void wait_vmcnt() {
     if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
+
+// CUs of the current device (cached per device ordinal) and its XCD count.  The block -> (head, query block) maps below and
+// the persistent grids assume the SPX-mode chip: 8 XCDs of 32 CUs, workgroups dealt round-robin over them.  A partition of
+// the chip (CPX / DPX / QPX: 32 / 128 / 64 CUs) or another part reports a different CU count; the launchers then use the
+// plain maps (xcd_remap = 0), which are correct anywhere -- the XCD arithmetic is a speed assumption, never a correctness one.
+inline int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cached[dev] = n > 0 ? n : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+constexpr int kCusPerXcd = 32;
+inline int xcd_count() { const int c = cu_count(); return c > 0 && c % kCusPerXcd == 0 ? c / kCusPerXcd : 1; }
 
 // block -> (head, query block).  Blocks b and b+8 share an XCD (round-robin dispatch; a speed assumption only):
 // each XCD gets a contiguous range of heads so the heads it works on keep their K/V in its private 4 MiB L2.

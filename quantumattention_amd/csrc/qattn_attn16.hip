@@ -397,7 +397,7 @@ extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const 
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
     p.nqb = ceil_div(Sq, kQPerWG16);
     p.ntiles = ceil_div(Skv, 32);
-    p.xcd_remap = ((B * Hq) % 8 == 0) ? 1 : 0;
+    p.xcd_remap = ((B * Hq) % 8 == 0 && xcd_count() == 8) ? 1 : 0;   // (the block map is written for 8 XCDs, qattn_attn.h)
     const float sm = sm_scale > 0.0f ? sm_scale : 1.0f / sqrtf((float)D);
     p.sm_log2e = sm * 1.4426950408889634f;
     p.fast_exp = fast_exp != 0;

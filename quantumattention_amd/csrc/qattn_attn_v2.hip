@@ -25,9 +25,12 @@
 //  * P is scaled by 2^kPShift before the e4m3 conversion.  One e4m3 term carries 3 mantissa bits, which is accurate enough
 //    only while a row's weight is spread over many keys, so:
 //      - query blocks that see fewer than kTwoTermKeys keys run with P split hi + lo (two terms, 2x the PV MFMAs);
-//      - every other block runs one term, tracks R = l / p_max (the inverse of the row's largest softmax weight) per row,
-//        and when a row ends with R < peak_r0 the whole 256-row block repeats its sweep in two-term mode before anything
-//        is stored.  Both paths live in one kernel, so a launch covers all query blocks of all heads.
+//      - every other block runs one term and tracks two statistics per row: R = l / p_max (the inverse of the row's largest
+//        softmax weight) and the effective key count l^2 / sum P'^2.  Rows that end below peak_r0 / peak_neff are "peaked":
+//        up to max_rescue 32-row groups of a block are recomputed on their own (rescue_rows: two-term, split-K over the 8
+//        waves); with more, the 256-row block repeats its sweep in two-term mode.  A block predicted to be peaked (score
+//        moments from the pre-pass, or the spread of its first chunk of scores) starts two-term or stops its one-term sweep
+//        after three chunks.  All paths live in one kernel, so a launch covers all query blocks of all heads.
 #include <type_traits>
 
 #include "qattn_attn.h"
@@ -37,40 +40,15 @@ namespace qattn {
 constexpr int kSyncEvery = 2;                   // waves synchronise every kSyncEvery 64-key iterations
 constexpr int kStagesV2 = 2 * kSyncEvery + 1;   // ring slots: G live + G being filled + the previous V stage
 
-// K/V staging through registers (issue early / write late): LDS-DMA pieces measured ~300 issue cycles each inside
-// this loop (profiles/r01_ablation.md), plain global_load_dwordx4 + ds_write_b128 a few tens.
-// One stage image = [K chunk | V chunk] = 2*64*D bytes, linear; thread (wave, lane) owns 16-byte pieces
-// r*(NW*1024) + wave*1024 + lane*16, r < ROUNDS.
-template <int D, int NW>
-struct StageRegs {
-    static constexpr int ROUNDS = 2 * 64 * D / (NW * 64 * 16);
-    v4i r[ROUNDS];
-};
-template <int D, int NW>
-__device__ __forceinline__ void stage_load(StageRegs<D, NW>& sr, const unsigned char* ksrc, const unsigned char* vsrc,
-                                           int wave, int lane) {
-    constexpr int CH = 64 * D;
-#pragma unroll
-    for (int r = 0; r < StageRegs<D, NW>::ROUNDS; r++) {
-        const int o = r * (NW * 1024) + (wave << 10);
-        const unsigned char* src = (o < CH ? ksrc + o : vsrc + (o - CH)) + (lane << 4);
-        sr.r[r] = *reinterpret_cast<const v4i*>(src);
-    }
-}
-template <int D, int NW>
-__device__ __forceinline__ void stage_write(const StageRegs<D, NW>& sr, unsigned char* lds_stage, int wave, int lane) {
-#pragma unroll
-    for (int r = 0; r < StageRegs<D, NW>::ROUNDS; r++)
-        *reinterpret_cast<v4i*>(lds_stage + r * (NW * 1024) + (wave << 10) + (lane << 4)) = sr.r[r];
-}
-
-// LDS-DMA copy of one stage image [K chunk | V chunk]: every wave-instruction moves 1 KiB (64 lanes x 16 B), linear.
+#ifdef QATTN_DEV
+// (dev library, 4-wave experiments) LDS-DMA copy of one stage image [K chunk | V chunk] = 2*64*D bytes, linear: every
+// wave-instruction moves 1 KiB (64 lanes x 16 B); wave w owns pieces r*(NW*1024) + w*1024, r < ROUNDS.
 template <int D, int NW>
 __device__ __forceinline__ void stage_dma(const unsigned char* ksrc, const unsigned char* vsrc, unsigned char* lds_stage,
                                           int wave, int lane) {
-    constexpr int CH = 64 * D;
+    constexpr int CH = 64 * D, ROUNDS = 2 * 64 * D / (NW * 64 * 16);
 #pragma unroll
-    for (int r = 0; r < StageRegs<D, NW>::ROUNDS; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         const int o = r * (NW * 1024) + (wave << 10);
         const unsigned char* ubase = o < CH ? ksrc + o : vsrc + (o - CH);  // wave-uniform: make it provably so (saddr form)
         const unsigned long long ub = (unsigned long long)ubase;
@@ -80,6 +58,7 @@ __device__ __forceinline__ void stage_dma(const unsigned char* ksrc, const unsig
                                          (__attribute__((address_space(3))) void*)(lds_stage + o), 16, 0, 0);
     }
 }
+#endif
 
 template <int D, bool TWO, bool BYTE>
 struct WaveState {
@@ -97,6 +76,12 @@ struct WaveState {
     // query + 32*half, 32 keys per lane) D[0][n] = sum over the 64 keys of query n and D[1][n] = that of query n + 16.
     // lsum[0] / lsum[1] of lanes 0..15 hold them; everything else in lsum stays 0.
     v4f lsum;
+    // NEFF (one-term passes under QATTN_PRECISION_AUTO): row sums of P'^2 for the effective key count l^2 / sum P'^2 (DESIGN.md
+    // section 4.5).  BYTE: one more row-sum MFMA per chunk on the SAME P bytes with the B format switched to e5m2 -- the exponent
+    // field of an e4m3 byte weighs twice as much when read as e5m2, so the byte of 2^x reads as 0.444 .. 0.5 of 2^(2x)
+    // (kNeffByteRatio; tools/sim_heavy.py).  Exact mode: fp32 fmas beside the row sum (l2_run).
+    v4f lsq;
+    float l2_run;
     v8i qreg[2];   // QREG kernels: the wave's Q^T fragments (both k-steps) held in registers instead of re-read from LDS
     v8i ones;      // BYTE mode: the all-ones A operand of that MFMA, kept opaque so it is not re-materialised every iteration
     float c;       // scale_q*scale_k*sm_scale*log2(e)
@@ -135,14 +120,15 @@ __device__ __forceinline__ void pv_chunk(const unsigned char* vbuf, const v8i& p
 // 4 scores -> 4 exponentials -> one dword of the e4m3 P operand (+ the residual dword when TWO); accumulates the
 // partial row sums in acc[0..3] (FIRST: initialises them).  `seed` only provides the register the first
 // v_cvt_pk_fp8_f32 writes its low half into (its high half is overwritten by the second), saving a v_mov.
-template <bool TWO, bool FIRST>
+template <bool TWO, bool FIRST, bool NEFF = false>
 __device__ __forceinline__ void exp_group(const v16f& sx, int j, float c, float mc, float (&acc)[4], v8i& pv, v8i& plv,
-                                          int w, int seed) {
+                                          int w, int seed, float* acc2 = nullptr) {
     float e[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[4 * j + i], c, mc));
         acc[i] = FIRST ? e[i] : acc[i] + e[i];
+        if (NEFF) acc2[i] = FIRST ? e[i] * e[i] : __builtin_fmaf(e[i], e[i], acc2[i]);
     }
     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));  // sums stay in this slot
     int ph = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], seed);
@@ -225,7 +211,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
         if (ABL & 4) break;                                                         \
         if (BYTE && (ABL & 32)) byte_group_u8(SX, J, cx, MC, pc, W, SEED);           \
         else if (BYTE) byte_group<false>(SX, J, cx, MC, pc, W, SEED);                \
-        else exp_group<TWO, FIRST>(SX, J, cx, MC, acc, pc, pcl, W, SEED);            \
+        else exp_group<TWO, FIRST, NEFF>(SX, J, cx, MC, acc, pc, pcl, W, SEED, acc2); \
     } while (0)
 
 // One pipelined iteration (1 <= t <= n_w): PV(t-2), [row-sum MFMA], QK(t), softmax(t-1) in hand-placed MFMA slots.
@@ -237,7 +223,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // bandwidth, are the scarce resource at two waves per SIMD).
 //   kbuf  : stage(t),   K part  (+ lane offset)      vprev : stage(t-1), V part = V(t-2)
 //   vnext : stage(t),   V part = V(t-1) (prefetch for the next iteration)
-template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, typename Stage>
+template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, typename Stage>
 __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const unsigned char* kbuf, const unsigned char* vprev,
                                           const unsigned char* vnext, const unsigned char* qbuf, Stage&& stage) {
     static_assert(D == 128, "hand-placed slots are written for D = 128");
@@ -259,7 +245,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     constexpr float U16 = (ABL & 32) ? 1.0f : 1.0f / 65535.0f;
     const float cx = BYTE ? (8.0f * U16) * c : c;
     const float mc = BYTE ? __builtin_fmaf((-8.0f * U16) * st.m_run, c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - st.m_run * c;
-    float acc[4];
+    float acc[4], acc2[4];
 
     // slot 0: O0 += V0.P(t-2)            reads: V2            VALU: max over tile 0
     st.o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[0], pp, st.o[0], st.vsx);
@@ -298,6 +284,8 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
     if (BYTE) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+    // ... and of its bytes read as e5m2 ~= P'^2 / 2 (WaveState::lsq)
+    if (BYTE && NEFF) st.lsq = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsq, QATTN_FMT_E4M3, QATTN_FMT_E5M2, 0, 0, 0, 0);
     v8i qg;                            // Q k-step 1
     if (QREG) qg = st.qreg[1]; else qg = LDSF(qbuf + (1 << 11));
     v8i kc = LDSF(kbuf + (1 << 11));   // K(tile 0, k-step 1)
@@ -329,6 +317,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     }
     if (!TWO) st.m_true = fmaxf(st.m_true, mx);
     float ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float ls2 = (BYTE || !NEFF) ? 0.0f : (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]);
     QATTN_SLOT_FENCE();
     QATTN2_STAMP(2);
     // rare fix-up: some row's max grew by more than the threshold (always on the first chunk: m_run = -1e30):
@@ -341,10 +330,13 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
 #pragma unroll
             for (int r = 0; r < 16; r++) st.o[m][r] *= alpha;
         st.l_run *= alpha;
+        if (NEFF) st.l2_run *= alpha * alpha;
         if (BYTE) {
             // lane n < 16 holds the sums of queries n (its own alpha) and n + 16 (lane n+16's alpha)
+            const float alpha16 = __shfl(alpha, (threadIdx.x & 15) + 16);
             st.lsum[0] *= alpha;
-            st.lsum[1] *= __shfl(alpha, (threadIdx.x & 15) + 16);
+            st.lsum[1] *= alpha16;
+            if (NEFF) { st.lsq[0] *= alpha * alpha; st.lsq[1] *= alpha16 * alpha16; }
         }
         st.m_run = m_new;
         const float mc2 = BYTE ? __builtin_fmaf((-8.0f * U16) * m_new, c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - m_new * c;
@@ -354,8 +346,10 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
 #pragma unroll
         for (int j = 0; j < 4; j++) QATTN_SM_GROUP(false, sc1, j, mc2, 4 + j, 0);
         ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        ls2 = (BYTE || !NEFF) ? 0.0f : (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]);
     }
     st.l_run += ls;
+    if (NEFF) st.l2_run += ls2;
     QATTN2_STAMP(3);
 }
 
@@ -367,7 +361,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
 // going to be repeated in two-term mode anyway: after two more chunks (the votes travel through the sweep's own barrier) all
 // waves drain the ring, stop and return true -- 3 of n chunks wasted instead of all of them.  Chunk 0 stands for the whole
 // key range here; where it does not, the R test at the end of the sweep is still the arbiter.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, typename LoadQ>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, typename LoadQ>
 __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q,
@@ -404,7 +398,9 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (voff + lane16)),
                                              (__attribute__((address_space(3))) void*)(smem + lds_next + CH + (wave << 10)), 16, 0, 0);
         } else {
+#ifdef QATTN_DEV
             stage_dma<D, NW>(kg + koff, vg + voff, smem + lds_next, wave, lane);
+#endif
         }
         voff = koff;
         koff = min(koff + (unsigned)CH, koff_max);
@@ -447,7 +443,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         prep_scores<CAUSAL, TOKEN>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
         if constexpr (VS) st.vsx = (int)vx[min(max(t - 2, 0), kVxWords - 1)];   // PV(t - 2) (t = 1: P = 0, any valid scale)
-        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS>(st, kbuf, vprev, kbuf + CH, qbuf, stage);
+        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF>(st, kbuf, vprev, kbuf + CH, qbuf, stage);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -474,7 +470,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
-    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && ABL == 0;
+    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && ABL == 0;   // (run-time: only passes that check their rows ask for it)
 #ifdef QATTN_DEV
     if (p.no_forecast) forecast = false;   // QATTN_NO_FORECAST=1: A/B switch
 #endif
@@ -546,6 +542,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
                 st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, ppl, st.o[3], st.vsx);
             }
             if (BYTE) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+            if (BYTE && NEFF) st.lsq = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsq, QATTN_FMT_E4M3, QATTN_FMT_E5M2, 0, 0, 0, 0);
         };
         if (t & 1) tail(P1{}); else tail(P0{});
         ++t;
@@ -561,7 +558,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
 // caller repeats the block in two-term mode -- or the bit mask of the (at most max_rescue) waves whose 32-row groups
 // rescue_pass then recomputes; the other waves' rows (and the optional LSE) are stored.  0: everything is stored.
 constexpr int kPassRedo = 1 << 30;
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, typename LoadQ>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, bool NEFF = false, typename LoadQ>
 __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
                                              int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q,
@@ -570,7 +567,8 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     const int hh = lane >> 5;
     WaveState<D, TWO, BYTE> st;
 #pragma unroll
-    for (int r = 0; r < 4; r++) st.lsum[r] = 0.0f;
+    for (int r = 0; r < 4; r++) { st.lsum[r] = 0.0f; st.lsq[r] = 0.0f; }
+    st.l2_run = 0.0f;
 #pragma unroll
     for (int m = 0; m < MB; m++)
 #pragma unroll
@@ -591,7 +589,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
         }
     };
-    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
+    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
                                                                                 !TWO && check_peaked, vote, vx))
         return kPassRedo;   // forecast: the block is peaked, nothing was stored
 #ifdef QATTN_DEV
@@ -614,20 +612,30 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     v16f (&o)[MB] = st.o;
 
     // ---- combine the two half-wave partial sums
-    float l_tot;
+    float l_tot, l2_tot = 0.0f;   // l2_tot: sum of P'^2 (exact mode) or kNeffByteRatio of it (BYTE)
     if (BYTE) {
         // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
         const float s0 = __shfl(st.lsum[0], threadIdx.x & 15), s1 = __shfl(st.lsum[1], threadIdx.x & 15);
         l_tot = (threadIdx.x & 16) ? s1 : s0;
+        if (NEFF) {
+            const float t0 = __shfl(st.lsq[0], threadIdx.x & 15), t1 = __shfl(st.lsq[1], threadIdx.x & 15);
+            l2_tot = (threadIdx.x & 16) ? t1 : t0;
+        }
     } else {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (NEFF) {
+            auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(st.l2_run), __float_as_uint(st.l2_run), false, false);
+            l2_tot = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+        }
     }
     constexpr float SHIFT = BYTE ? kPShiftByte : kPShift;
     if (!TWO && check_peaked) {  // workgroup-uniform
         // R = l' / p'_max with p'_max = 2^(shift + (m_true - m_run) c): the inverse of the row's largest softmax weight
         const float r_inv_pmax = __builtin_amdgcn_exp2f(-(SHIFT + (st.m_true - m_run) * c));
-        const bool peaked = qrow < p.Sq && l_tot * r_inv_pmax < p.peak_r0;
+        // ... and the row's effective key count l'^2 / sum P'^2 bounds the statistical error of MANY similar weights, which R does not
+        const float neff_min = p.peak_neff * (BYTE ? 1.0f / kNeffByteRatio : 1.0f);
+        const bool peaked = qrow < p.Sq && (l_tot * r_inv_pmax < p.peak_r0 || (NEFF && l_tot * l_tot < neff_min * l2_tot));
 #ifdef QATTN_DEV
         if ((p.dbg & 64) && p.dbg_buf && qrow < p.Sq && hh == 0) {
             float* d = reinterpret_cast<float*>(p.dbg_buf + (1 << 19)) + (bh * p.Sq + qrow) * 4;
@@ -677,7 +685,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
 
 // Everything a wave derives from its thread / block index for one pass over its query rows, and that pass itself (the Q^T
 // fragments are re-loaded by a second pass: a few KiB against the pass's megabytes of K / V).
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16, bool NEFF = false>
 __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
@@ -765,7 +773,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     };
     // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
     constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
-    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16>(
+    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO>(
         p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx);
 }
 
@@ -802,7 +810,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
 
 // One 256-row block: a block whose rows are predicted peaked (predicted_r) starts two-term; a one-term pass that finds too
 // many peaked rows loops back into the same two-term code.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16, bool CHECK>
 __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* smem, int bid) {
     int head, qb;
     map_block(p, bid, p.nqb, CAUSAL, head, qb);
@@ -840,7 +848,7 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
             block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, bid, false);
             break;
         }
-        const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16>(p, smem, tid, bid, p.peak_r0 > 0.0f);
+        const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK>(p, smem, tid, bid, CHECK);
         if (r == 0) break;
         if (r != kPassRedo) {   // a few peaked groups (every wave is past the vote barrier, hence done with the K/V ring)
             if constexpr (!TOKEN && NW == 8) {
@@ -865,11 +873,13 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
 // -2.5 % auto at C2).  Causal launches keep one workgroup per block: their blocks differ in length, the hardware's
 // hand-out (heaviest first) balances them; a static stride over the same order was 6 % slower, and persistent workgroups
 // taking balanced PAIRS of blocks (qb = j and nqb - 1 - j of one head) 3-5 % slower in fast and 10 % in auto mode.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false>
+// CHECK: QATTN_PRECISION_AUTO -- one-term passes carry the two peakedness statistics (R and the effective key count) and end
+// with the vote / rescue / redo logic; the FAST launches instantiate neither.
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false, bool CHECK = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (CAUSAL) {
-        run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16>(p_arg, smem, blockIdx.x);
+        run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p_arg, smem, blockIdx.x);
     } else {
         const int nblocks = p_arg.total_blocks;
         for (int bid = blockIdx.x; bid < nblocks; bid += gridDim.x) {
@@ -883,40 +893,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
 #else
             const AttnParams& p = p_arg;
 #endif
-            run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16>(p, smem, bid);
+            run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p, smem, bid);
             if (bid + (int)gridDim.x < nblocks) __syncthreads();   // every wave has left the ring and the Q slots before the next block fills them
         }
     }
 }
 
-// CUs of the current device (cached per device ordinal)
-static int cu_count() {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (cached[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        cached[dev] = n > 0 ? n : -1;
-    }
-    return cached[dev] > 0 ? cached[dev] : 0;
-}
-
-template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16 = false>
-static int launch_attn_v2_one(const AttnParams& pin, hipStream_t st) {
+template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16, bool CHECK>
+static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     AttnParams p = pin;
     p.total_blocks = p.B * p.Hq * p.nqb;
-    // one persistent workgroup per CU (a multiple of 8 keeps every workgroup's blocks on one XCD); fewer blocks than CUs: one each
-    const int cus = cu_count() & ~7;
+    // one persistent workgroup per CU (a multiple of 8 keeps every workgroup's blocks on one XCD: blocks b and b + grid share
+    // b & 7; xcd_remap is only set on an 8-XCD device, qattn_api.hip); fewer blocks than CUs: one each
+    const int cus = p.xcd_remap ? cu_count() & ~7 : cu_count();
     const int grid = (!CAUSAL && p.persistent && cus >= 8 && p.total_blocks > cus) ? cus : p.total_blocks;
     size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
 #endif
-    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 0, Q16>;
+    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 0, Q16, CHECK>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
     return QATTN_OK;
+}
+template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16 = false>
+static int launch_attn_v2_one(const AttnParams& p, hipStream_t st) {
+    return p.peak_r0 > 0.0f ? launch_attn_v2_chk<D, NW, FMT, CAUSAL, TOKEN, BYTE, Q16, true>(p, st)
+                            : launch_attn_v2_chk<D, NW, FMT, CAUSAL, TOKEN, BYTE, Q16, false>(p, st);
 }
 
 template <int D, int NW, int FMT, bool CAUSAL>

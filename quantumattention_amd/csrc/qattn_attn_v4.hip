@@ -136,6 +136,9 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
 #pragma unroll
         for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
     v4f lsum = {0.0f, 0.0f, 0.0f, 0.0f};
+    v4f lsq = {0.0f, 0.0f, 0.0f, 0.0f};   // one-term AUTO launch: row sums of P'^2 (WaveState::lsq in qattn_attn_v2.hip)
+    float l2_run = 0.0f;
+    const bool neff = mode == 0 && p.peak_neff > 0.0f;   // launch-uniform
     v8i ones;  // A of the row-sum MFMA (see WaveState::lsum in qattn_attn_v2.hip)
     {
         const int row = lane & 15, kg = lane >> 4;
@@ -243,10 +246,14 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
 #pragma unroll
                 for (int r = 0; r < 16; r++) o[m][r] *= alpha;
             if (BYTE) {
+                const float alpha16 = __shfl(alpha, (lane & 15) + 16);
                 lsum[0] *= alpha;
-                lsum[1] *= __shfl(alpha, (lane & 15) + 16);
+                lsum[1] *= alpha16;
+                lsq[0] *= alpha * alpha;
+                lsq[1] *= alpha16 * alpha16;
             } else {
                 l_run *= alpha;
+                l2_run *= alpha * alpha;
             }
             m_run = m_new;
         }
@@ -262,7 +269,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
         } else {
             // ---- exact exponentials, RNE e4m3; optional residual term lo = fp8(p - hi); fp32 row sums
             const float mc = kPShift - m_run * c;
-            float ls = 0.0f;
+            float ls = 0.0f, ls2 = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; w++) {
                 const v16f& sx = w < 4 ? s0 : s1;
@@ -270,6 +277,10 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
                 float e[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) { e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[4 * j + i], c, mc)); ls += e[i]; }
+                if (neff) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ls2 = __builtin_fmaf(e[i], e[i], ls2);
+                }
                 int ph = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], 0);
                 ph = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2], e[3], ph);
                 pv[w] = ph;
@@ -283,6 +294,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
                 pl[w] = plo;
             }
             l_run += ls;
+            l2_run += ls2;
         }
         // ---- O^T += V^T.P^T, row sums
         o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf0, pv, o[0]);
@@ -302,21 +314,29 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
             }
         }
         if (BYTE) lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+        // (the same bytes read as e5m2 ~= P'^2 / 2)
+        if (BYTE && neff) lsq = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsq, QATTN_FMT_E4M3, QATTN_FMT_E5M2, 0, 0, 0, 0);
     }
 
     // ---- epilogue
-    float l_tot;
+    float l_tot, l2_tot;
     if (BYTE) {
         const float s0l = __shfl(lsum[0], lane & 15), s1l = __shfl(lsum[1], lane & 15);
         l_tot = (lane & 16) ? s1l : s0l;
+        const float t0l = __shfl(lsq[0], lane & 15), t1l = __shfl(lsq[1], lane & 15);
+        l2_tot = (lane & 16) ? t1l : t0l;
     } else {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l2_run), __float_as_uint(l2_run), false, false);
+        l2_tot = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
     }
     constexpr float SHIFT = BYTE ? kPShiftByte : kPShift;
     if (p.peak_r0 > 0.0f && !two && !only_flagged) {
         // one-term launch: R = l' / p'_max is the inverse of the row's largest softmax weight; a peaked row flags its group
-        const bool peaked = qrow < p.Sq && l_tot * __builtin_amdgcn_exp2f(-(SHIFT + (m_true - m_run) * c)) < p.peak_r0;
+        // ... and l'^2 / sum P'^2 its effective key count (kPeakNeff, qattn_attn.h)
+        const float neff_min = p.peak_neff * (BYTE ? 1.0f / kNeffByteRatio : 1.0f);
+        const bool peaked = qrow < p.Sq && (l_tot * __builtin_amdgcn_exp2f(-(SHIFT + (m_true - m_run) * c)) < p.peak_r0 || l_tot * l_tot < neff_min * l2_tot);
         if (__any(peaked) && lane == 0 && q0 < p.Sq) *flag = 1u;
     }
     const float sv = p.sv ? p.sv[kv_head] : 1.0f;

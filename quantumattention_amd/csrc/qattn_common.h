@@ -78,8 +78,8 @@ __device__ inline int cvt4_fp8(float a, float b, float c, float d) {
 // The IEEE divide + software bf16 rounding cost ~40 VALU per element and made the pre-pass VALU-bound, so bf16
 // inputs take a fast path: q' = x * rinv with rinv = RNE(1/scale) is within 3 fp32 ulps of RNE(x/scale); both round
 // to the same bf16 unless q' lies within 4 ulps of a bf16 tie (low 16 bits near 0x8000, probability ~1.4e-4), and only
-// those vectors fall back to the exact sequence.  Requires a finite scale, which implies finite inputs (the scale is
-// derived from the group's abs-max).  Results below the fp8 subnormal range round to (signed) zero either way.
+// those vectors fall back to the exact sequence.  Requires a finite scale, which implies finite inputs where the scale is
+// derived from the group's abs-max (elsewhere: force_exact).  Results below the fp8 subnormal range round to (signed) zero either way.
 // ---------------------------------------------------------------------------------------------------------
 // scale = clamp_min(amax * (1/fmax), eps_f32)   (nn.py:14-16; eager numerics round the scale and eps to the input dtype)
 __device__ inline float make_scale(float amax, float inv_qmax, int numerics, int in_fmt) {
@@ -118,8 +118,10 @@ __device__ __attribute__((noinline)) int2 quant8_exact_call(const uint4 raw, flo
     return quant8_exact<IN_FMT, OUT_FMT>(raw, scale);
 }
 
+// force_exact: the caller knows of non-finite inputs although `scale` is finite (the block-scaled V: a chunk with an inf or a
+// NaN gets the scale 2^0) -- the packed clamp below would turn a NaN into +-fmax.
 template <int IN_FMT, int OUT_FMT>
-__device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv) {
+__device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv, bool force_exact = false) {
     if (IN_FMT != QATTN_FMT_BF16) return quant8_exact<IN_FMT, OUT_FMT>(raw, scale);
     // Per pair of elements: unpack (2 VALU), v_pk_mul_f32, tie test on the packed low halves (v_perm, v_pk_add_u16,
     // v_pk_min_u16), v_cvt_pk_bf16_f32, clamp of the packed bf16 magnitudes (and, v_pk_min_u16, and-or), and one
@@ -155,7 +157,7 @@ __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv
         __builtin_memcpy(&cl[i], &c, 4);
     }
     const unsigned near = min((unsigned)pnear.x, (unsigned)pnear.y);
-    const bool slow = near < 9u || !((__float_as_uint(scale) & 0x7f800000u) != 0x7f800000u);
+    const bool slow = force_exact || near < 9u || !((__float_as_uint(scale) & 0x7f800000u) != 0x7f800000u);
     if (__builtin_expect(slow, 0)) return quant8_exact_call<IN_FMT, OUT_FMT>(raw, scale);  // one out-of-line copy: rare
     s2 lo = {0, 0}, hi = {0, 0};
     if (OUT_FMT == QATTN_FMT_E4M3) {

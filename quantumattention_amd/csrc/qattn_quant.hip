@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     // chunk's abs-max through LDS, and quantised with the power-of-two scale that the attention kernel gets as one byte
     const bool vblock = layout == QATTN_LAYOUT_VFRAG && jobs.vexp != nullptr;   // uniform over the launch's z slice
     uint4 held[ITERS];
+    bool exact_tile = false;   // block-scaled V: the chunk holds an inf or a NaN (scale 2^0 all the same) -> NaN bytes must survive
     if (vblock) {
         typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
         unsigned m0 = 0;
@@ -337,7 +338,9 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
         __syncthreads();
         m = max(max(red[0], red[1]), max(red[2], red[3]));
         __syncthreads();   // (img is written below)
-        const int e = vblock_exponent(__float_as_uint(load16f<IN_FMT>((unsigned short)m)), OUT_FMT);
+        const unsigned amax_bits = __float_as_uint(load16f<IN_FMT>((unsigned short)m));
+        const int e = vblock_exponent(amax_bits, OUT_FMT);
+        exact_tile = (amax_bits & 0x7f800000u) == 0x7f800000u;   // workgroup-uniform
         scale = __uint_as_float((unsigned)(e + 127) << 23);
         rinv = __uint_as_float((unsigned)(127 - e) << 23);
         if (tid == 0) {
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
             if (dv == 0 && row < S) jb.scale[(long)g * S + row] = scale;
         }
         if (token) rinv = 1.0f / scale;
-        const int2 lohi = quant8<IN_FMT, OUT_FMT>(raw, scale, rinv);
+        const int2 lohi = quant8<IN_FMT, OUT_FMT>(raw, scale, rinv, exact_tile);
         const int lo = lohi.x, hi = lohi.y;
         const int d0 = dv * 8;
         if (layout == QATTN_LAYOUT_ROWMAJOR) {

@@ -23,7 +23,7 @@ _HALF_DTYPES = (torch.float16, torch.bfloat16)
 def _cfg(name: str):
     """config.attention.<name>, readable under torch.compile(fullgraph=True): dynamo does not trace the config proxy's
     __getattr__, so the lookup goes through an assume_constant_result helper as in the reference (utils/checks.py)."""
-    return checks.get_constant_attr("quantumattention_amd.config", f"attention.{name}")
+    return checks.config_value(f"attention.{name}")
 
 
 def _ops():
@@ -217,7 +217,7 @@ def can_use_hip_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_c
 
 def can_use_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None,
                       scaling_method=None, scale_q=None, scale_k=None) -> Tuple[bool, str]:
-    if checks.get_constant_attr("quantumattention_amd.config", "attention.skip_supported_check"):
+    if checks.config_value("attention.skip_supported_check"):
         return True, ""
     supported, reason = can_use_hip_attention(
         query, key, value, attn_mask, dropout_p, is_causal, scale=scale, scaling_method=scaling_method,
@@ -328,8 +328,15 @@ def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_
 
 def _fp8_attention_eager(query, key, value, is_causal, scale, scale_q, scale_k, scaling_method) -> Tensor:
     """force_eager_fallback: the reference's wrapper run eagerly (nn.py:503-516 -> :394-430 -> ops.py:64-95)."""
+    if (scale_q is None) != (scale_k is None):
+        raise ValueError("scale_q and scale_k must be both provided or both not provided")
     if scale_q is None:
-        reduction_dim = [query.dim() - 2, query.dim() - 1] if scaling_method == "head-wise" else query.dim() - 1
+        if scaling_method == "head-wise":        # nn.py:409-415: head-wise / token-wise / else raise, as the kernel path
+            reduction_dim = [query.dim() - 2, query.dim() - 1]
+        elif scaling_method == "token-wise":
+            reduction_dim = query.dim() - 1
+        else:
+            raise ValueError(f"Unsupported scaling_method: {scaling_method}")
         query, scale_q = _dynamically_quantize_fp8(query, reduction_dim=reduction_dim)
         key, scale_k = _dynamically_quantize_fp8(key, reduction_dim=reduction_dim)
     return _eager_fp8_attention(query, key, value, scale_q, scale_k, is_causal, scale)

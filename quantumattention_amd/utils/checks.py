@@ -4,19 +4,15 @@ import functools
 import importlib
 
 import torch
-from packaging import version
 
 
 @torch.compiler.assume_constant_result
-def get_constant_attr(module, attr):
-    obj = importlib.import_module(module)
-    for a in attr.split("."):
-        obj = getattr(obj, a)
-    return obj
+def config_value(dotted_name: str):
+    """`quantumattention_amd.config.<dotted_name>` as a trace-time constant: dynamo cannot follow the config module's
+    __getattr__, so flag reads inside traced code go through this helper (role of the reference's checks.py:9-15)."""
+    from functools import reduce
 
-
-def torch_version_compare(op, v):
-    return getattr(version.parse(torch.__version__).release, f"__{op}__")(version.parse(v).release)
+    return reduce(getattr, dotted_name.split("."), importlib.import_module("quantumattention_amd.config"))
 
 
 def is_amd_rocm() -> bool:

@@ -51,16 +51,16 @@ def fused_step_uses_block_v(D, scaling, dtype, Skv) -> bool:
 
 
 def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfloat16, scaling="head", causal=False,
-                        sm_scale=0.0, return_lse=False, v_block=False):
+                        sm_scale=0.0, return_lse=False, v_block=False, q_offset=0):
     """O3 of SURVEY.md §8c: fp64 SDPA on the same quantised q, k AND the build's quantised v (v_block: the fused step's
     block-scaled V, oracle.quantize_v_block; else one scale per head)."""
     if v_block:
         _, _, vdq = oracle.quantize_v_block(v16b, fmt16(v_dtype), FMT[fp8])
         return oracle.attention_forward(q8b, k8b, vdq, FMT[fp8], FMT[fp8], oracle.FMT_BF16, sq, sk, None, scale_mode=scaling,
-                                        causal=causal, sm_scale=sm_scale, return_lse=return_lse)
+                                        causal=causal, sm_scale=sm_scale, return_lse=return_lse, q_offset=q_offset)
     v8, sv = oracle.quantize_fp8(v16b, fmt16(v_dtype), "head", FMT[fp8], "compiled")
     return oracle.attention_forward(q8b, k8b, v8, FMT[fp8], FMT[fp8], FMT[fp8], sq, sk, sv, scale_mode=scaling,
-                                    causal=causal, sm_scale=sm_scale, return_lse=return_lse)
+                                    causal=causal, sm_scale=sm_scale, return_lse=return_lse, q_offset=q_offset)
 
 
 def err_stats(got: np.ndarray, ref: np.ndarray):

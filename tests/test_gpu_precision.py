@@ -2,7 +2,7 @@
 
 One e4m3 term of P carries 3 mantissa bits; that is enough only while a row's softmax weight is spread over many keys.
 Trained attention heads have score std 2..5: a handful of keys carry the row.  These tests scale q (score std x2, x3, x5),
-mix sharpness per row, and plant groups of equally heavy keys; the oracle is fp64 SDPA on the same quantised q, k, v.
+mix sharpness per row, and plant groups of similar keys that carry the rows; the oracle is fp64 SDPA on the same quantised q, k, v.
 Stated tolerance (BASELINE.json north_star): max-abs < 2^-6, NOT scaled by |O| (S >= 1024 here).
 
   precision="auto"      (default) must meet 2^-6 on every case: peaked blocks are detected (R = l / p_max < 24) and redone
@@ -16,6 +16,7 @@ import torch
 
 import oracle
 import quantumattention_amd as qa
+from quantumattention_amd import _native
 from tests.gpu_utils import bits16, err_stats, oracle_for_fp8_path, out_to_f32
 
 pytestmark = pytest.mark.gpu
@@ -65,22 +66,72 @@ def test_peaked_rows_meet_the_stated_bound(S, D, sharp, causal):
         assert mx_fast > TOL, ("one-term P was expected to break the bound on these rows", mx_fast)
 
 
-def test_groups_of_equally_heavy_keys():
-    """Adversarial for a max-weight statistic: K keys share the row's weight equally (R ~ K).  K = 8, 16 must be caught by
-    the R < 24 test; K = 64 is left on the one-term path, where 64 independent roundings average out."""
-    torch.manual_seed(3)
-    S, D = 4096, 128
-    for K in (8, 16, 64):
-        q, k, v = torch.randn(1, 2, S, D), torch.randn(1, 2, S, D), torch.randn(1, 2, S, D)
-        u = torch.randn(D)
-        u /= u.norm()
-        idx = torch.randperm(S)[:K]
-        q = q + 4.0 * u                       # every query has a common component ...
-        k[:, :, idx] = 0.25 * k[:, :, idx] + 4.0 * u   # ... that K keys share: their scores sit ~16/sqrt(D)*... above the rest
-        q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
-        ref = _oracle(q, k, v, False)
-        mx, rms = err_stats(_run(q, k, v, False, "auto"), ref)
-        assert mx < TOL, (K, mx, rms)
+def _heavy_inputs(S, D, K, late, seed, gap=9.0, H=1):
+    """K keys that CARRY every row that sees them: their scores sit `gap` nats above an N(0,1) background with 0.15..0.3 nats of
+    spread among themselves (tools/sim_heavy.py).  q = q0 + a u, heavy keys = a u + jitter, a^2 / sqrt(D) = gap; every
+    other key (and q0) has no component along u, so the background scores stay N(0,1).  late: heavy keys only among the last
+    256 positions (nothing of them in the first chunks: the kernel's first-chunk forecast cannot see them)."""
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = (torch.randn(1, H, S, D, generator=g) for _ in range(3))
+    u = torch.randn(D, generator=g)
+    u /= u.norm()
+    a = (gap * D ** 0.5) ** 0.5
+    jitter = 0.15 if K <= 40 else 0.2 if K <= 64 else 0.3
+    idx = (S - 256 + torch.randperm(256, generator=g)[:K]) if late else torch.randperm(S, generator=g)[:K]
+    k = k - (k @ u)[..., None] * u
+    q = q - (q @ u)[..., None] * u + a * u
+    kh = torch.randn(1, H, K, D, generator=g)
+    k[:, :, idx] = jitter * (kh - (kh @ u)[..., None] * u) + a * u
+    return q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16), idx
+
+
+def _separate_calls(q, k, v, causal, precision):
+    """quantise, then attend pre-quantised operands (qattn_fp8_attention_forward): this caller has no pre-pass moments, so the
+    starting-mode prediction sees unit variance and only the sweep's own statistics can find the rows."""
+    H, S = k.shape[1], k.shape[2]
+    q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q.cuda(), k.cuda(), v.cuda())
+    return out_to_f32(_native.fp8_attention_forward(q8, kf, vf, sq, sk, sv, Hkv=H, Skv=S, out_dtype=torch.bfloat16, is_causal=causal,
+                                                    precision=precision))
+
+
+HEAVY_CASES = [(K, late, causal, D) for K in (8, 16, 32, 40, 48, 64, 100) for late in (False, True) for causal in (False, True)
+               for D in (128, 64) if D == 128 or (K in (16, 48, 100) and not (late and causal))]
+
+
+@pytest.mark.parametrize("K,late,causal,D", HEAVY_CASES, ids=lambda x: str(x))
+def test_many_similar_heavy_keys(K, late, causal, D):
+    """VERDICT r2 weak #1.  R = 1 / w_max bounds the LARGEST weight only: K similar keys that carry a row have R ~ K, pass R >= 24
+    from K ~ 30 on, and still cost ~ 0.16 / sqrt(K) with one-term P (0.026 at K = 40, 0.017 at K = 100).  The second statistic
+    is the effective key count l^2 / sum P'^2 (kPeakNeff; the sum of squares comes from one more row-sum MFMA on the same P
+    bytes read as e5m2).  `auto` must meet 2^-6 unscaled through the fused step and through the separate C calls (no moments),
+    with the heavy keys spread uniformly and placed late only; `fast` is asserted to break the bound where the model says so."""
+    S = 4096
+    q, k, v, idx = _heavy_inputs(S, D, K, late, seed=100 + K)
+    # the construction does what it says: fp64 softmax of the 16-bit inputs
+    sc = (q[0, 0].double() @ k[0, 0].double().T) / D ** 0.5
+    if causal:
+        sc = sc.masked_fill(torch.arange(S)[None, :] > torch.arange(S)[:, None], -float("inf"))
+    w = torch.softmax(sc, dim=1)
+    held = w[:, idx].sum(1)                    # weight the K keys hold, per row
+    R = 1.0 / w.max(dim=1).values
+    frac_r = float((R < 24).float().mean())   # rows the R test alone catches
+    if not causal:
+        assert float(held.median()) > 0.9, float(held.median())
+        assert frac_r > 0.9 if K <= 16 else frac_r < 0.02 if K >= 40 else True, (K, frac_r)   # K >= 40: R does not see them
+    else:                                      # causal rows are carried once they see most of the K keys
+        assert float((held > 0.9).float().mean()) > (0.01 if late else 0.9)
+    q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    ref_fused = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal, v_block=D == 128)
+    ref_sep = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal) if D == 128 else ref_fused
+    mx_fused = err_stats(_run(q, k, v, causal, "auto"), ref_fused)[0]
+    mx_sep = err_stats(_separate_calls(q, k, v, causal, "auto"), ref_sep)[0]
+    assert mx_fused < TOL and mx_sep < TOL, (K, late, causal, D, mx_fused, mx_sep, frac_r)
+    if not causal and K <= 64:
+        mx_fast = err_stats(_separate_calls(q, k, v, causal, "fast"), ref_sep)[0]
+        assert mx_fast > TOL, ("one-term P was expected to break the bound on these rows", K, mx_fast)
+    if not causal and D == 128:   # every block is found peaked and repeats in two-term mode: ACCURATE's bits
+        np.testing.assert_array_equal(_separate_calls(q, k, v, causal, "auto"), _separate_calls(q, k, v, causal, "accurate"))
 
 
 def test_flat_rows_keep_the_one_term_result_bit_for_bit():
@@ -197,7 +248,7 @@ def test_lse_reference_layout_and_convention():
 
 def test_config5_at_its_stated_size_B4_H40_S16384_e5m2_causal():
     """BASELINE config 5 at full size (only B = 1 had run): finite, deterministic, batch-shard equivalent, and
-    within the bound on an oracle slice (one head: the first 1280 rows and, via a non-causal Sq != Skv call, the last 256)."""
+    within the bound on oracle slices of four heads (first rows, a mid-sequence band, the last rows; oracle q_offset)."""
     torch.manual_seed(5)
     B, H, S, D = 4, 40, 16384, 128
     q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
@@ -206,14 +257,13 @@ def test_config5_at_its_stated_size_B4_H40_S16384_e5m2_causal():
         assert torch.isfinite(out).all()
         assert torch.equal(out, qa.fp8_attn_func(q, k, v, is_causal=True))                              # determinism
         assert torch.equal(out[2:3], qa.fp8_attn_func(q[2:3], k[2:3], v[2:3], is_causal=True))          # batch-shard equivalence
-    b, h, top = 3, 17, 1280
-    qs, ks, vs = q[b:b + 1, h:h + 1].cpu(), k[b:b + 1, h:h + 1].cpu(), v[b:b + 1, h:h + 1].cpu()
-    q8, sq = oracle.quantize_fp8(bits16(qs), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
-    k8, sk = oracle.quantize_fp8(bits16(ks), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
-    ref_top = oracle_for_fp8_path(q8[:, :, :top], k8, bits16(vs), sq, sk, fp8="e5m2", causal=True, v_block=True)
-    mx, rmse = err_stats(out_to_f32(out[b, h, :top]), ref_top[0, 0])
-    assert mx < TOL * max(1.0, float(np.abs(ref_top).max()) / 2.0) and rmse < 3e-3, (mx, rmse)   # |O| > 2 only on the first rows
-    tail = slice(S - 256, S)
-    ref_tail = oracle_for_fp8_path(q8[:, :, tail], k8, bits16(vs), sq, sk, fp8="e5m2", causal=False)
-    got_last = out_to_f32(out[b, h, S - 1])      # the last causal row sees every key = the non-causal row
-    assert np.abs(got_last - ref_tail[0, 0, -1]).max() < TOL
+    # oracle slices (more than one head): four heads across the batch; of each the first 1280 rows, a mid-sequence band
+    # (rows 8192..8447 see 8193..8448 keys) and the last 256 rows, all against the fused step's block-scaled V
+    for b, h in ((0, 0), (1, 39), (2, 13), (3, 17)):
+        qs, ks, vs = q[b:b + 1, h:h + 1].cpu(), k[b:b + 1, h:h + 1].cpu(), v[b:b + 1, h:h + 1].cpu()
+        q8, sq = oracle.quantize_fp8(bits16(qs), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
+        k8, sk = oracle.quantize_fp8(bits16(ks), oracle.FMT_BF16, "head", oracle.FMT_E5M2)
+        for r0, r1 in ((0, 1280), (8192, 8448), (S - 256, S)):
+            ref = oracle_for_fp8_path(q8[:, :, r0:r1], k8[:, :, :r1], bits16(vs[:, :, :r1]), sq, sk, fp8="e5m2", causal=True, v_block=True, q_offset=r0)
+            mx, rmse = err_stats(out_to_f32(out[b, h, r0:r1]), ref[0, 0])
+            assert mx < TOL * max(1.0, float(np.abs(ref).max()) / 2.0) and rmse < 3e-3, (b, h, r0, mx, rmse)   # |O| > 2 only on the first rows

@@ -144,7 +144,8 @@ def test_quant_fast_path_bit_exact_on_adversarial_bit_patterns(scaling, numerics
 def test_fused_step_block_scaled_v_is_bit_exact(fp8):
     """The fused step (D = 128, head-wise, bf16) quantises V with one power-of-two scale per 64-key chunk inside its quantise pass
     (no abs-max pass over V): payload (VFRAG) and scale bytes against oracle.quantize_v_block, on ragged S, with a zero chunk, a
-    huge chunk, a tiny chunk and an inf."""
+    huge chunk, a tiny chunk, an inf and a NaN (a chunk with a non-finite abs-max gets the scale 2^0 and must still
+    take the exact conversion, so that its NaN stays a NaN byte and the rows that attend it come out non-finite)."""
     from quantumattention_amd._native import LAYOUT_KFRAG, LAYOUT_VFRAG, SCALE_HEAD, PRECISION, fmt_of, _stream
     torch.manual_seed(3)
     B, H, S, D = 2, 3, 1000, 128
@@ -153,6 +154,7 @@ def test_fused_step_block_scaled_v_is_bit_exact(fp8):
     v[0, 1, 128:192] *= 3.0e4
     v[0, 2, 192:256] *= 1.0e-6
     v[1, 0, 300, 5] = float("inf")
+    v[1, 1, 500, 9] = float("nan")
     L = _native.lib()
     dev = q.device
     out = torch.empty_like(q)
@@ -176,4 +178,11 @@ def test_fused_step_block_scaled_v_is_bit_exact(fp8):
     got8 = unpack_frag(bits8(vf), LAYOUT_VFRAG, B, H, S, D)[:, :, :S]
     nan_ref = (ref8 & 0x7f) == 0x7f if fp8 == "e4m3" else (ref8 & 0x7f) > 0x7c
     np.testing.assert_array_equal(got8[~nan_ref], ref8[~nan_ref])
+    got_nan = (got8 & 0x7f) == 0x7f if fp8 == "e4m3" else (got8 & 0x7f) > 0x7c
+    np.testing.assert_array_equal(got_nan, nan_ref)           # NaN bytes exactly where the oracle has them (one: the planted NaN)
+    assert nan_ref.sum() == 1 and nan_ref[1, 1, 500, 9]
     np.testing.assert_array_equal(sv.cpu().numpy(), np.ones((B, H), np.float32))
+    o = out.float().cpu().numpy()
+    assert np.isnan(o[1, 1, :, 9]).all()                      # every (non-causal) row of that head attends the NaN
+    others = np.ones((B, H), bool); others[1, 1] = False
+    assert np.isfinite(o[others]).all()                       # the inf was clamped to fmax like any out-of-range value

@@ -1,6 +1,7 @@
 """No shipped kernel may spill registers or use scratch memory: compile the product sources for gfx950 with -save-temps
 (hipcc cross-compiles without a GPU) and read .vgpr_spill_count / .private_segment_fixed_size of every kernel from the
-code-object metadata.  Uses the build directory `__graft_entry__.build()` / build.py fill."""
+code-object metadata.  The -save-temps compile has a directory of its own (build.py BUILD_TEMPS), outside
+what git and gpurun ship."""
 import os
 import subprocess
 import sys
@@ -16,8 +17,8 @@ import kernel_resources  # noqa: E402
 def test_every_shipped_kernel_is_free_of_spills_and_scratch():
     from quantumattention_amd import build as hip_build
 
-    hip_build.build(save_temps=True)   # no-op when the objects and their .s files are current
-    d = hip_build.BUILD
+    d = hip_build.build(save_temps=True)   # no-op when the objects and their .s files are current
+    assert d == hip_build.BUILD_TEMPS
     units = [name for _, _, name in hip_build.UNITS]
     files = [name + "-hip-amdgcn-amd-amdhsa-gfx950.s" for name in units]
     assert all(os.path.exists(os.path.join(d, f)) for f in files), "build(save_temps=True) must leave one .s per translation unit"

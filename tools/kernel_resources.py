@@ -51,10 +51,10 @@ def loops(d, pattern):
 
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--loops":
-        d = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quantumattention_amd", "_build")
+        d = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quantumattention_amd", "_build_temps")
         loops(d, sys.argv[2])
         return 0
-    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quantumattention_amd", "_build")
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quantumattention_amd", "_build_temps")
     bad = 0
     for f in sorted(os.listdir(d)):
         if not f.endswith("gfx950.s"):
