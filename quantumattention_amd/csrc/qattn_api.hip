@@ -71,7 +71,7 @@ struct AttnCall {
     int B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode, is_causal;
     float sm_scale;
     int precision, lse_layout;
-    unsigned* flags;   // nullptr or one word per (b, h, 32-row group) of THIS call
+    void* attn_ws;     // nullptr or the attention workspace of THIS call (attn_ws_sched / attn_ws_flags below)
     const unsigned* vexp;         // fused step with a block-scaled V (else nullptr)
     const float *ssq_q, *ssq_k;   // fused step, head-wise AUTO: the heads' partial sums of squares from the pre-pass (else nullptr)
     int ssq_n;
@@ -80,6 +80,10 @@ struct AttnCall {
     float* sq_out;
     int q_numerics;
 };
+
+// attention workspace = [SchedState of the hand-scheduled kernel's causal launches | one flag word per (b, h, 32-row group)]
+size_t attn_ws_sched_bytes(int, int, int) { return (sched_bytes() + 15) / 16 * 16; }
+size_t attn_ws_flag_bytes(int B, int Hq, int Sq) { return sizeof(unsigned) * (size_t)B * Hq * ceil_div(Sq, 32); }
 
 // launches the attention kernel(s) of one call on `st`; ds != nullptr: bracket them with the profile events
 int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
@@ -122,7 +126,8 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.vexp = a.vexp;
     p.ssq_n = a.ssq_n; p.ssq_stride = kMomentSplits;
     p.var_mul = sm * sm / ((float)a.Sq * (float)a.Skv * (float)a.D);
-    p.flags = a.flags;
+    p.sched = (SchedState*)a.attn_ws;
+    p.flags = a.attn_ws ? (unsigned*)((unsigned char*)a.attn_ws + attn_ws_sched_bytes(a.B, a.Hq, a.Sq)) : nullptr;
     p.lse_stride = (long)qattn_lse_row_stride(a.Sq, a.lse_layout);
     p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
     p.q16 = (const unsigned char*)a.q16; p.q_amax_part = a.q_amax_part; p.sq_out = a.sq_out; p.q_numerics = a.q_numerics;
@@ -131,10 +136,11 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     const DevEnv& e = dev_env();
     p.exact_exp = e.exact_exp;
     p.two_term_keys = e.two_term_keys;
-    if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = e.peak_r0;
+    if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = getenv("QATTN_PEAK_R0") ? (float)atof(getenv("QATTN_PEAK_R0")) : e.peak_r0;   // (read per call: tools/ab.py variants)
     if (a.precision == QATTN_PRECISION_AUTO && getenv("QATTN_PEAK_NEFF")) p.peak_neff = (float)atof(getenv("QATTN_PEAK_NEFF"));
     if (getenv("QATTN_MAX_RESCUE")) p.max_rescue = atoi(getenv("QATTN_MAX_RESCUE"));
     if (getenv("QATTN_PERSISTENT")) p.persistent = atoi(getenv("QATTN_PERSISTENT"));
+    if (getenv("QATTN_NO_SCHED")) p.sched = nullptr;   // static block order, rescues on the spot (round 2's behaviour)
     if (getenv("QATTN_NO_FORECAST")) p.no_forecast = atoi(getenv("QATTN_NO_FORECAST"));
     p.waves = !use_v2 ? kWaves : e.waves;
     p.nqb = ceil_div(a.Sq, p.waves * kQPerWave);
@@ -271,7 +277,7 @@ extern "C" float qattn_last_attention_ms(void) {
 
 extern "C" size_t qattn_attention_workspace_bytes(int B, int Hq, int Sq) {
     if (B <= 0 || Hq <= 0 || Sq <= 0) return 0;
-    return sizeof(unsigned) * (size_t)B * Hq * ceil_div(Sq, 32);   // one word per 32-row group
+    return attn_ws_sched_bytes(B, Hq, Sq) + attn_ws_flag_bytes(B, Hq, Sq);
 }
 
 extern "C" size_t qattn_lse_row_stride(int Sq, int lse_layout) {
@@ -284,18 +290,19 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
                                            int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt, int v_fmt, int out_fmt,
                                            int scale_mode, int is_causal, float sm_scale, int precision, int lse_layout,
                                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (B <= 0 || Hq <= 0 || Sq <= 0) return QATTN_ERR_INVALID_ARG;
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    if ((D != 64 && D != 128 && D != 256) || Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;   // (before the size of the workspace is judged)
     const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
     if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
     AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
-               is_causal, sm_scale, precision, lse_layout, have_ws ? (unsigned*)workspace : nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
+               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
     return attention_impl(a, (hipStream_t)stream, ds);
 }
 
 extern "C" size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int Hkv, int Sq) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0) return 0;
-    // [abs-max bits of q, k, v | peaked-block flags of the attention call], the second part 16-byte aligned
+    // [abs-max bits of q, k, v | the attention call's workspace], the second part 16-byte aligned
     return (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16 + qattn_attention_workspace_bytes(B, Hq, Sq);
 }
 
@@ -319,7 +326,7 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     // the attention of group g.  The 512-thread attention workgroups leave 32-48 VGPRs per SIMD, the pre-pass waves displace
     // them instead of sharing the CU, and the chip is power-limited on the attention kernel: the step got 19-31 % SLOWER.)
     unsigned* ws = (unsigned*)workspace;
-    unsigned* flags = (unsigned*)((unsigned char*)workspace + (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16);
+    void* attn_ws = (unsigned char*)workspace + (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16;
     const bool moments = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD;
     // block-scaled V where the hand-scheduled kernel runs (its PV products take the chunk's scale byte) and a head has at most
     // kMomentSplits chunks: V then needs no abs-max pass
@@ -333,7 +340,7 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     if (rc != QATTN_OK) return rc;
     const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
     AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
-               fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, flags,
+               fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, attn_ws,
                v_block ? mom.vexp : nullptr, moments ? mom.part_q : nullptr, moments ? mom.part_k : nullptr, mom.nsplit, fuse_q ? q : nullptr, fuse_q ? mom.amax_q : nullptr, fuse_q ? scale_q : nullptr, numerics};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);

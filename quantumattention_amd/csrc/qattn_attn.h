@@ -42,15 +42,19 @@ constexpr float kVarDeadband = 1.5f;
 // 4096 exp(1.2^2 / 2 - z 1.2) = 24 at z = 4.9.
 constexpr float kPeakZWide = 4.9f;
 constexpr int kVxWords = 256;                // V chunk scale bytes a block keeps in LDS (block-scaled V: Skv <= 16384)
-__device__ inline float predicted_r(float nkeys, float var, float z) { return nkeys * __expf(0.5f * var - z * sqrtf(var)); }
+__device__ inline float predicted_r(float nkeys, float var, float z) {
+    // (opaque 0.5: left to the compiler, {0.5, z} becomes a loop-invariant register pair of a v_pk_mul_f32 that is hoisted to the
+    // top of the persistent kernels' block loop and spilled -- the kernels sit at the 256-register limit)
+    float half = 0.5f;
+    asm volatile("" : "+v"(half));
+    return nkeys * __expf(half * var - z * sqrtf(var));
+}
 // a head's sum of squares from its partial sums, the same value in every lane of every wave (fixed order: lane l adds
-// l, l + 64, ...; then the xor tree)
+// l, l + 64, ...; then a fixed reduction tree)
 __device__ inline float sum_partials(const float* part, int n, int lane) {
     float t = 0.0f;
     for (int i = lane; i < n; i += 64) t += part[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    return t;
+    return wave_allsum(t);
 }
 
 struct AttnParams {
@@ -82,6 +86,11 @@ struct AttnParams {
     float var_mul;               // score variance of head (bh, kvh) ~= sum(ssq_q[bh]) * sum(ssq_k[kvh]) * var_mul
     int total_blocks;            // B * Hq * nqb (set by the launcher); the grid may be smaller: workgroups walk blocks bid, bid + gridDim.x, ...
     int persistent;              // one workgroup per CU instead of one per block
+    // Dynamic block hand-out of the hand-scheduled kernel's causal launches (qattn_attn_v2.hip; nullptr: static).  `sched` lives in
+    // the call's workspace and is zeroed by the launcher every call: the workgroups of a persistent launch draw their next
+    // block from per-XCD counters (SchedState below).
+    struct SchedState* sched;
+    int sched_nq;                // block counters in use: 8 (one per XCD label blockIdx.x & 7) with xcd_remap, else 1
     int no_forecast;             // dev switch
     const unsigned* vexp;        // fused step with a block-scaled V (else nullptr): E8M0 byte of every 64-key V chunk, [B*Hkv][ssq_stride]
     int max_rescue;              // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
@@ -99,6 +108,67 @@ struct AttnParams {
     int dbg;         // 16 = stamp per-wave sweep cycles into dbg_buf
 #endif
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Block hand-out inside one persistent causal launch of the D = 128 kernel.  The only datum that travels between workgroups is
+// a block number drawn from a counter (relaxed agent-scope atomics; nothing a block reads is written in the launch, so no
+// release / acquire is involved):
+//   next[x]   blocks handed out from queue x beyond the first gridDim.x / nq (every workgroup starts on block blockIdx.x);
+//             x = blockIdx.x & 7 labels the workgroups that share an XCD, so a head's blocks keep their K / V in one L2
+// One 32-byte header to zero per launch.
+// Measured and dropped (round 3, profiles/r03/sched_queue.md): a queue of the 32-row groups to rescue, emptied by workgroups
+// that have run out of blocks.  A rescue away from the XCD whose L2 holds the head's K / V is 2-3x slower (latency-bound,
+// chunk by chunk), a rescue cannot be split, and the workgroup that found the group is as fast as any idle one of its XCD:
+// deferring every rescue to the end of a causal launch cost +40 %, handing over only the groups of a workgroup's last block
+// +12 % (S = 4096), against rescues on the spot.
+// ---------------------------------------------------------------------------------------------------------
+struct SchedState {
+    unsigned next[8];
+};
+inline size_t sched_bytes() { return sizeof(SchedState); }   // a multiple of 16
+
+#define QATTN_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// the next block of queue x, else of another queue (a workgroup that has finished its XCD's blocks helps elsewhere); -1: none left
+__device__ inline int sched_next_block(SchedState* s, int nq, int x, int bpq, int first) {
+    const int idx = (int)__hip_atomic_fetch_add(&s->next[x], 1u, QATTN_RLX_AGENT) + first;
+    if (idx < bpq) return idx * nq + x;
+    unsigned nx[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) nx[k] = __hip_atomic_load(&s->next[k & (nq - 1)], QATTN_RLX_AGENT);   // all in flight together
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        const int xx = (x + k) & (nq - 1);
+        if (k >= nq || (int)nx[xx] + first >= bpq) continue;
+        const int j = (int)__hip_atomic_fetch_add(&s->next[xx], 1u, QATTN_RLX_AGENT) + first;
+        if (j < bpq) return j * nq + xx;
+    }
+    return -1;
+}
+
+// The verdict on one row at the end of a one-term sweep.  l = sum P', l2 = sum P'^2 (BYTE: kNeffByteRatio of
+// it), r_inv_pmax = 1 / P'_max, all in the row's final reference.
+//   * N_eff = l^2 / l2 < peak_neff: many similar weights, a statistical error that R does not see.
+//   * R = l / P'_max < peak_r0: one weight so large that its own rounding may exceed the budget -- UNLESS that weight is exact.
+//     A key whose score beat the row's reference max by more than the deferred-rescale threshold took the fix-up branch and
+//     became the reference: it was exponentiated at x = shift exactly, its byte (or RNE e4m3 value) is exactly 2^shift, and
+//     no later rescale touched the row (m_run == m_true from then on), so its contribution carries no rounding error at
+//     all.  The row is then judged by its REST: with the top key taken out of both sums, l_r^2 / l2_r >= peak_r0^2 says that
+//     no other weight exceeds 1 / peak_r0 -- the same guarantee the R test gives an ordinary row.  On N(0,1) data nearly
+//     every row with R < 24 is one outlier key of exactly this kind (tools/sim_exact_top.py: 100 % at n = 4096, 77 % at 2048).
+template <bool BYTE, bool NEFF>
+__device__ __forceinline__ bool row_is_peaked(const AttnParams& p, float l, float l2, float r_inv_pmax, bool top_is_reference) {
+    static_assert(kPShift == 5.0f && kPShiftByte == 5.0f, "p_top below is 2^shift");
+    bool peaked = l * r_inv_pmax < p.peak_r0;
+    if (NEFF) {
+        constexpr float ratio = BYTE ? 1.0f / kNeffByteRatio : 1.0f;
+        constexpr float p_top = 32.0f;                                          // 2^shift, and its square as the l2 sum holds it:
+        constexpr float p_top2 = BYTE ? 0.5f * p_top * p_top : p_top * p_top;   //   the byte of 2^integer read as e5m2 is exactly half the square
+        const float l_r = l - p_top, l2_r = fmaxf(l2 - p_top2, 0.0f);
+        const bool rest_flat = top_is_reference && l_r * l_r >= p.peak_r0 * p.peak_r0 * ratio * l2_r;
+        peaked = (peaked && !rest_flat) || l * l < p.peak_neff * ratio * l2;
+    }
+    return peaked;
+}
 
 // PV product with a block-scaled V: `scale_a` is the E8M0 byte (e + 127) of the V chunk in A (one value for both 32-wide K
 // blocks of every row here; profiles/r02_mfma_scale_probe.log), B = P unscaled.  VS = false: the plain product.
@@ -223,7 +293,10 @@ __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool cau
 
 // In-place fix-ups of a finished S^T chunk before its softmax (both rare or cheap, kept out of the hot block):
 // token-wise key scales (inductor/kernels/attention.py:395) and the ragged-tail / causal-diagonal mask.
-template <bool CAUSAL, bool TOKEN>
+// RAGGED = false: the caller knows that the chunk lies inside the key range (every chunk but a head's last one); the test
+// then needs nothing of AttnParams -- inside the hand-scheduled loop p.Skv was re-read from the kernel-argument segment every
+// iteration (scalar registers are short there) and its s_waitcnt lgkmcnt(0) drained the operand reads in flight.
+template <bool CAUSAL, bool TOKEN, bool RAGGED = true>
 __device__ __forceinline__ void prep_scores(v16f& s0, v16f& s1, const AttnParams& p, int k0, int q0, int qrow, int hh,
                                             const float* skt) {
     if (TOKEN) {
@@ -239,7 +312,7 @@ __device__ __forceinline__ void prep_scores(v16f& s0, v16f& s1, const AttnParams
                 sx[4 * j + 0] *= w.x; sx[4 * j + 1] *= w.y; sx[4 * j + 2] *= w.z; sx[4 * j + 3] *= w.w;
             }
     }
-    const bool need_mask = (k0 + 64 > p.Skv) || (CAUSAL && k0 + 63 > q0);  // wave-uniform
+    const bool need_mask = (RAGGED && k0 + 64 > p.Skv) || (CAUSAL && k0 + 63 > q0);  // wave-uniform
     if (__builtin_expect(need_mask, 0)) {
 #pragma unroll
         for (int r = 0; r < 32; r++) {
@@ -256,8 +329,9 @@ __device__ __forceinline__ void prep_scores(v16f& s0, v16f& s1, const AttnParams
 // exponentials and two-term P, the key range split over the NW = 8 waves of a workgroup (each takes a contiguous run of
 // 64-key chunks, reads the K / V fragments straight from global memory / L2 and keeps a partial {O, m, l}); the partials
 // are merged pairwise through LDS (three rounds, 4 slots of SLOT bytes at `smem`) and wave 0 stores the rows.  Called
-// from inside the D = 128 kernel (the rescued wave's Q^T fragments come from its LDS slots, the idle K/V ring holds the
-// merge) and from rescue_groups_kernel for the templated kernel's launches.  About 0.3 of a 256-row block's sweep.
+// from inside the D = 128 kernel (by whichever workgroup takes the queue item; the idle K/V ring holds the merge) and from
+// rescue_groups_kernel for the templated kernel's launches; the Q^T fragments come from global memory through `qfrag`.
+// About 0.3 of a 256-row block's sweep.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxRescueWaves = 2;   // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode
 
@@ -273,7 +347,7 @@ __device__ __forceinline__ v8i gload_frag(const unsigned char* base) {
 template <int D>
 constexpr int rescue_slot_bytes() { return ((D / 32) * 16 + 2) * 64 * 4; }   // one wave's partial {O^T, m, l}
 
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QLDS = false, typename QFrag>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QLDS = false, bool VSCALE = false, typename QFrag>
 __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                             int r0, int wave, int lane, long bh, long kv_head, float c, const float* skt, QFrag&& qfrag,
                                             const unsigned* vx = nullptr) {   // vx: the V chunks' scale bytes (LDS), nullptr: unscaled V
@@ -381,7 +455,7 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
             }
 #pragma unroll
             for (int m = 0; m < VB; m++) {
-                if constexpr (QLDS) {   // (the D = 128 kernel's call: V may be block-scaled)
+                if constexpr (VSCALE) {   // (the D = 128 kernel's call: V may be block-scaled)
                     o[m0 + m] = mfma_pv<V_FMT, QATTN_FMT_E4M3, true>(vf[m], ph, o[m0 + m], vsx);
                     o[m0 + m] = mfma_pv<V_FMT, QATTN_FMT_E4M3, true>(vf[m], pl, o[m0 + m], vsx);
                 } else {

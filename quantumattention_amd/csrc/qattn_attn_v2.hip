@@ -31,6 +31,8 @@
 //        waves); with more, the 256-row block repeats its sweep in two-term mode.  A block predicted to be peaked (score
 //        moments from the pre-pass, or the spread of its first chunk of scores) starts two-term or stops its one-term sweep
 //        after three chunks.  All paths live in one kernel, so a launch covers all query blocks of all heads.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "qattn_attn.h"
@@ -225,7 +227,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 //   vnext : stage(t),   V part = V(t-1) (prefetch for the next iteration)
 template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, typename Stage>
 __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const unsigned char* kbuf, const unsigned char* vprev,
-                                          const unsigned char* vnext, const unsigned char* qbuf, Stage&& stage) {
+                                          const unsigned char* vnext, const unsigned char* qbuf, Stage&& stage, const unsigned* vx_next = nullptr) {
     static_assert(D == 128, "hand-placed slots are written for D = 128");
     // ABL (timing-only ablations, results wrong): 4 = no softmax VALU, 8 = no LDS fragment reads (operands = a fixed register set)
     auto LDSF = [&](const unsigned char* ptr) -> v8i { if (ABL & 8) return st.vpre[0]; return lds_read_frag(ptr); };
@@ -301,6 +303,9 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     // slot 6: S1 = K(1,0).Q0             reads: next iteration's V0                  VALU: group 5
     sn1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf, sn1);
     st.vpre[0] = LDSF(vnext + (0 << 11));
+    // block-scaled V: the scale byte of the NEXT iteration's PV products, requested here (this iteration's four are issued) -- read
+    // at the top of its own iteration it put a whole LDS round trip in front of the first MFMA of every iteration
+    if (VS) st.vsx = (int)*vx_next;
     QATTN_SM_GROUP(false, sc1, 1, mc, 5, pc[4]);
     QATTN_SLOT_FENCE();
     // slot 7: S0 += K(0,1).Q1            reads: next iteration's V1                  VALU: group 6
@@ -333,7 +338,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
         if (NEFF) st.l2_run *= alpha * alpha;
         if (BYTE) {
             // lane n < 16 holds the sums of queries n (its own alpha) and n + 16 (lane n+16's alpha)
-            const float alpha16 = __shfl(alpha, (threadIdx.x & 15) + 16);
+            const float alpha16 = __uint_as_float(swizzle_xor16(__float_as_uint(alpha)));   // (lanes 0..15 get lanes 16..31, no lane-index register)
             st.lsum[0] *= alpha;
             st.lsum[1] *= alpha16;
             if (NEFF) { st.lsq[0] *= alpha * alpha; st.lsq[1] *= alpha16 * alpha16; }
@@ -391,7 +396,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     const unsigned koff_max = (unsigned)(p.nchunks - 1) * CH;
     unsigned koff = 0, voff = 0, lds_next = 0;
     const unsigned lane16 = (unsigned)lane << 4;
-    auto dma_next = [&]() {
+    auto dma_next = [&]() __attribute__((always_inline)) {
         if (NW == 8) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (koff + lane16)),
                                              (__attribute__((address_space(3))) void*)(smem + lds_next + (wave << 10)), 16, 0, 0);
@@ -412,7 +417,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         if (g < T) dma_for(g);
     load_q();  // the wave's Q^T rows (global -> [quantise ->] LDS / registers) travel while the first K/V stages do
     unsigned slot_cur = 0, slot_prev = 0;
-    auto sync_iter = [&](int t, bool in_step = false) -> const unsigned char* {
+    auto sync_iter = [&](int t, bool in_step = false) __attribute__((always_inline)) -> const unsigned char* {
         (void)in_step;
         if (t % kSyncEvery == 0) {
             wait_vmcnt<0>();  // this wave's pieces of stages t .. t+G-1 have landed
@@ -429,24 +434,29 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         }
         return smem + slot_cur + frag_lane_off;
     };
-    auto advance = [&]() {  // slot_cur / slot_prev: LDS offsets of stage(t) / stage(t-1), advanced once per iteration
+    auto advance = [&]() __attribute__((always_inline)) {  // slot_cur / slot_prev: LDS offsets of stage(t) / stage(t-1), advanced once per iteration
         slot_prev = slot_cur;
         slot_cur = slot_cur + STAGE == kStagesV2 * STAGE ? 0u : slot_cur + STAGE;
     };
     auto do_stage = [&](int) {};
-    auto full = [&](auto par_tag, int t) {
+    // ragged_tag: may chunk t - 1 (the one this iteration exponentiates) reach past the key range?  Only a head's last chunk can;
+    // non-causal sweeps say so statically for all iterations but the last (prep_scores)
+    auto full = [&](auto par_tag, int t, auto ragged_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const unsigned char* kbuf = sync_iter(t, true);
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         advance();
         QATTN2_STAMP(0);
-        prep_scores<CAUSAL, TOKEN>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
+        prep_scores<CAUSAL, TOKEN, RAGGED>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
-        if constexpr (VS) st.vsx = (int)vx[min(max(t - 2, 0), kVxWords - 1)];   // PV(t - 2) (t = 1: P = 0, any valid scale)
-        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF>(st, kbuf, vprev, kbuf + CH, qbuf, stage);
+        // (VS) iteration t + 1 multiplies V(t - 1): its scale byte is requested during iteration t (t = 1 runs on the initial 2^0: P = 0)
+        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF>(st, kbuf, vprev, kbuf + CH, qbuf, stage, VS ? vx + min(t - 1, kVxWords - 1) : nullptr);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    using Inner = std::integral_constant<bool, CAUSAL>;   // an iteration whose chunk t - 1 is not the head's last one (causal: no static knowledge kept)
+    using Last = std::integral_constant<bool, true>;
 #ifdef QATTN_DEV
     for (int i = 0; i < 6; i++) st.seg[i] = 0;
     st.tlast = __builtin_amdgcn_s_memtime();
@@ -470,7 +480,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
-    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && ABL == 0;   // (run-time: only passes that check their rows ask for it)
+    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && (ABL & ~512) == 0;   // (run-time: only passes that check their rows ask for it)
 #ifdef QATTN_DEV
     if (p.no_forecast) forecast = false;   // QATTN_NO_FORECAST=1: A/B switch
 #endif
@@ -486,8 +496,8 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
                 su += st.s[0][0][r] + st.s[0][1][r];
                 sq = __builtin_fmaf(st.s[0][0][r], st.s[0][0][r], __builtin_fmaf(st.s[0][1][r], st.s[0][1][r], sq));
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { su += __shfl_xor(su, off); sq += __shfl_xor(sq, off); }
+            su = wave_allsum(su);
+            sq = wave_allsum(sq);
             const float mean = su * (1.0f / 2048.0f), cn = st.c * 0.6931471805599453f;
             const float var = fmaxf(sq * (1.0f / 2048.0f) - mean * mean, 0.0f) * cn * cn;
             const int nkeys = CAUSAL ? min(p.Skv, q0 + kQPerWave) : p.Skv;
@@ -496,27 +506,33 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
             if (lane == 0) vote[wave] = mine ? 1u : 0u;
         }
     }
-    if constexpr (FORECAST) {
-        if (forecast) {   // (n_w >= 3 here) the first pair of iterations, peeled so that the loop below stays free of the test
-            full(P1{}, 1);
-            full(P0{}, 2);   // starts with the barrier that publishes the votes
-            t = 3;
-            int nf = 0;
+    // iterations t <= n_w - 1 exponentiate chunks <= n_w - 2; the last one or two iterations (the head's last chunk is among
+    // them for a wave that sees it) run the copies with the ragged-tail test.  (Loop + loop + if, all with static parities:
+    // an if / else-if over the leftover count made the compiler keep the S / P arrays in scratch memory.)
+    for (; t + 1 <= n_w - 1; t += 2) {
+        full(P1{}, t, Inner{});
+        full(P0{}, t + 1, Inner{});   // (t = 1: starts with the barrier that publishes the forecast votes)
+        if constexpr (FORECAST) {
+            // the votes are read after the first pair of iterations (forecast: n_w >= 3 and n_wg >= 16, so this trip exists for every
+            // wave of the workgroup); one scalar test per trip instead of a peeled copy of the pair, which cost registers
+            if (forecast && t == 1) {
+                int nf = 0;
 #pragma unroll
-            for (int w = 0; w < NW; w++) nf += vote[w] != 0u ? 1 : 0;
-            if (__builtin_amdgcn_readfirstlane(nf) > p.max_rescue) {
-                wait_vmcnt<0>();   // the stages requested at that barrier
-                __builtin_amdgcn_s_barrier();
-                return true;
+                for (int w = 0; w < NW; w++) nf += vote[w] != 0u ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(nf) > p.max_rescue) {
+                    wait_vmcnt<0>();   // the stages requested at that barrier
+                    __builtin_amdgcn_s_barrier();
+                    return true;
+                }
             }
         }
     }
-    for (; t + 1 <= n_w; t += 2) {
-        full(P1{}, t);
-        full(P0{}, t + 1);
+    for (; t + 1 <= n_w; t += 2) {  // at most one trip
+        full(P1{}, t, Last{});
+        full(P0{}, t + 1, Last{});
     }
     if (t <= n_w) {  // n_w odd
-        full(P1{}, t);
+        full(P1{}, t, Last{});
         ++t;
     }
     // t = n_w + 1: the last chunk's PV (V(t-2) lives in stage(t-1); its row blocks 0,1 are already in vpre)
@@ -524,7 +540,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         (void)sync_iter(t);
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         const v8i fc = lds_read_frag(vprev + (2 << 11)), fd = lds_read_frag(vprev + (3 << 11));
-        if constexpr (VS) st.vsx = (int)vx[min(t - 2, kVxWords - 1)];
+        // (VS: st.vsx already holds the scale of V(t - 2) = V(n_w - 1), requested by the last full step)
         // two fully static copies: any run-time choice between st.p[0] and st.p[1] (even by value) ends up as a pointer
         // phi that keeps the P registers in scratch memory
         auto tail = [&](auto par_tag) {
@@ -577,6 +593,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     st.m_true = -1.0e30f;
     st.l_run = 0.0f;
     st.c = c;
+    st.vsx = 127;   // 2^0
 #ifdef QATTN_DEV
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -615,11 +632,11 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     float l_tot, l2_tot = 0.0f;   // l2_tot: sum of P'^2 (exact mode) or kNeffByteRatio of it (BYTE)
     if (BYTE) {
         // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
-        const float s0 = __shfl(st.lsum[0], threadIdx.x & 15), s1 = __shfl(st.lsum[1], threadIdx.x & 15);
-        l_tot = (threadIdx.x & 16) ? s1 : s0;
+        const float s0 = bcast_low16(st.lsum[0]), s1 = bcast_low16(st.lsum[1]);
+        l_tot = (lane & 16) ? s1 : s0;
         if (NEFF) {
-            const float t0 = __shfl(st.lsq[0], threadIdx.x & 15), t1 = __shfl(st.lsq[1], threadIdx.x & 15);
-            l2_tot = (threadIdx.x & 16) ? t1 : t0;
+            const float t0 = bcast_low16(st.lsq[0]), t1 = bcast_low16(st.lsq[1]);
+            l2_tot = (lane & 16) ? t1 : t0;
         }
     } else {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
@@ -633,9 +650,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     if (!TWO && check_peaked) {  // workgroup-uniform
         // R = l' / p'_max with p'_max = 2^(shift + (m_true - m_run) c): the inverse of the row's largest softmax weight
         const float r_inv_pmax = __builtin_amdgcn_exp2f(-(SHIFT + (st.m_true - m_run) * c));
-        // ... and the row's effective key count l'^2 / sum P'^2 bounds the statistical error of MANY similar weights, which R does not
-        const float neff_min = p.peak_neff * (BYTE ? 1.0f / kNeffByteRatio : 1.0f);
-        const bool peaked = qrow < p.Sq && (l_tot * r_inv_pmax < p.peak_r0 || (NEFF && l_tot * l_tot < neff_min * l2_tot));
+        const bool peaked = qrow < p.Sq && row_is_peaked<BYTE, NEFF>(p, l_tot, l2_tot, r_inv_pmax, st.m_true == m_run);
 #ifdef QATTN_DEV
         if ((p.dbg & 64) && p.dbg_buf && qrow < p.Sq && hh == 0) {
             float* d = reinterpret_cast<float*>(p.dbg_buf + (1 << 19)) + (bh * p.Sq + qrow) * 4;
@@ -773,18 +788,21 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     };
     // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
     constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
-    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO>(
+    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO && !(ABL & 512)>(   // (ABL 512: dev timing of the statistic's cost)
         p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx);
 }
 
-// The rescue of a block's flagged 32-row groups as a pass of its own: everything is derived afresh from the (opaque)
-// thread index and the block id, so that nothing of the sweep is live here and nothing of this is live in the sweep.  The
-// rescued wave's Q^T fragments are still parked in its LDS slots; the K/V ring is idle and holds the prefetch and the merge.
+// The rescue of a block's flagged 32-row groups as a pass of its own, run by whichever workgroup took the queue item (or by the
+// block's own workgroup in a static launch): everything is derived afresh from the (opaque) thread index and the block id, so
+// that nothing of a sweep is live here and nothing of this is live in a sweep.  The rescued rows' Q^T fragments are fetched
+// from global memory (fused step: the 16-bit rows, quantised with the quant8 sequence of the sweep's prologue: the same
+// bytes), the head's V chunk scales are re-read into LDS; the K/V ring is idle and holds the prefetch and the merge.
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool Q16>
 __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, unsigned flagged) {
     constexpr int CH = 64 * D;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
     int head, qb;
     map_block(p, bid, p.nqb, CAUSAL, head, qb);
     const int b = head / p.Hq, h = head % p.Hq;
@@ -792,26 +810,58 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
     const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
     const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
-    float c;
+    unsigned* vx = reinterpret_cast<unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D) + 16;
+    float c, scale_q16 = 1.0f;
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        c = p.sm_log2e * make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.ssq_stride, p.ssq_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16) * p.sk[kv_head];
+        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.ssq_stride, p.ssq_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        c = p.sm_log2e * scale_q16 * p.sk[kv_head];
+        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.ssq_stride + i] : 127u;
+        __syncthreads();
     } else {
         c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
     }
     for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
-        const int fw = __builtin_ctz(rest);
-        const unsigned char* qsrc = smem + kStagesV2 * 2 * 64 * D + fw * ((D / 64) << 11) + ((lane >> 5) << 10) + ((lane & 31) << 4);
-        rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL, false, true>(p, smem, kg, vg, qb * (NW * kQPerWave) + fw * kQPerWave, wave, lane, bh, kv_head, c,
-                                                               nullptr, [&](int s_) { return lds_read_frag(qsrc + (s_ << 11)); },
-                                                               Q16 ? reinterpret_cast<const unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D) + 16 : nullptr);
+        const int r0 = qb * (NW * kQPerWave) + __builtin_ctz(rest) * kQPerWave, row = r0 + ql;
+        const bool qvalid = row < p.Sq;
+        auto qfrag = [&](int s_) -> v8i {
+            if (Q16) {
+                const float rinv = 1.0f / scale_q16;
+                const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? row : 0)) * D + hh * 32) * 2) + s_ * 8;
+                int2 w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint4 raw = qp[i];
+                    if (!qvalid) raw = make_uint4(0, 0, 0, 0);
+                    w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw, scale_q16, rinv);
+                }
+                return v8i{w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y, w[3].x, w[3].y};
+            } else {
+                const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? row : 0)) * D) + hh * 32 + s_ * 64;
+                v4i lo = *reinterpret_cast<const v4i*>(qp), hi = *reinterpret_cast<const v4i*>(qp + 16);
+                if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
+                return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+        // parked in this lane's own slots of the workgroup's Q area (behind the ring), as the sweep does: held in registers for the
+        // rescue loop they cost the causal fused instantiation two spilled registers
+        unsigned char* qslot = smem + kStagesV2 * 2 * 64 * D + wave * ((D / 64) << 11) + (hh << 10) + (ql << 4);
+#pragma unroll
+        for (int s_ = 0; s_ < D / 64; s_++) {
+            const v8i f = qfrag(s_);
+            *reinterpret_cast<v4i*>(qslot + (s_ << 11)) = v4i{f[0], f[1], f[2], f[3]};
+            *reinterpret_cast<v4i*>(qslot + (s_ << 11) + 512) = v4i{f[4], f[5], f[6], f[7]};
+        }
+        rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, nullptr,
+                                                                    [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, Q16 ? vx : nullptr);
     }
 }
 
 // One 256-row block: a block whose rows are predicted peaked (predicted_r) starts two-term; a one-term pass that finds too
 // many peaked rows loops back into the same two-term code.
+// Returns the bit mask of the block's 32-row groups (waves) that still need rescue_pass (0: none; CHECK launches only).
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16, bool CHECK>
-__device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* smem, int bid) {
+__device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char* smem, int bid, int tid) {   // tid: an opaque copy of threadIdx.x
     int head, qb;
     map_block(p, bid, p.nqb, CAUSAL, head, qb);
     // One copy of each pass.  Every per-lane value is re-derived inside block_pass from an opaque copy of the thread index, so
@@ -820,7 +870,9 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
     if (!two) {
         float var = 1.0f;
         if (p.ssq_q) {
-            const int lane = threadIdx.x & 63, kvh = (head / p.Hq) * p.Hkv + (head % p.Hq) / (p.Hq / p.Hkv);
+            // (lane from the caller's opaque thread index: derived from threadIdx.x it is hoisted out of the kernel's block loop
+            // as a 64-bit byte offset and spilled)
+            const int lane = tid & 63, kvh = (head / p.Hq) * p.Hkv + (head % p.Hq) / (p.Hq / p.Hkv);
             var = sum_partials(p.ssq_q + (long)head * p.ssq_stride, p.ssq_n, lane) * sum_partials(p.ssq_k + (long)kvh * p.ssq_stride, p.ssq_n, lane) * p.var_mul;
             if (!(var >= kVarDeadband)) var = 1.0f;
         }
@@ -828,7 +880,6 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
         const float z = var >= kVarDeadband ? fmaxf(p.peak_z, kPeakZWide) : p.peak_z;
         two = __builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, z) < kPeakR0 ? 1 : 0) != 0;   // (every lane holds the same value)
     }
-    int tid = threadIdx.x;
 #ifdef QATTN_DEV
     const unsigned long long dbg_entry = (p.dbg & 16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     auto dbg_exit = [&]() {
@@ -842,6 +893,7 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
 #else
     auto dbg_exit = [&]() {};
 #endif
+    unsigned to_rescue = 0u;
     for (;;) {
         asm volatile("" : "+v"(tid));
         if (two) {
@@ -851,15 +903,13 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
         const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK>(p, smem, tid, bid, CHECK);
         if (r == 0) break;
         if (r != kPassRedo) {   // a few peaked groups (every wave is past the vote barrier, hence done with the K/V ring)
-            if constexpr (!TOKEN && NW == 8) {
-                asm volatile("" : "+v"(tid));
-                rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16>(p, smem, tid, bid, (unsigned)r);
-            }
+            to_rescue = (unsigned)r;
             break;
         }
         two = true;  // many rows of this block are peaked: the block repeats in two-term mode
     }
     dbg_exit();
+    return to_rescue;
 }
 
 // QK_FMT / V_FMT: QATTN_FMT_E4M3 (0) or QATTN_FMT_E5M2 (1) == the MFMA's cbsz/blgp selector.
@@ -867,36 +917,77 @@ __device__ __forceinline__ void run_block(const AttnParams& p, unsigned char* sm
 // Q16: the fused step (qattn_fp8_quant_attention_forward): Q arrives as bf16 and is quantised here, row by row, with the
 // same quant8 sequence as the pre-pass (bit-identical q8), from the head's abs-max bits -- the pre-pass then neither
 // re-reads Q nor writes q8, and this kernel reads 2 instead of 1 byte per Q element once.
-// One launch covers every query block of every head.  Non-causal launches are PERSISTENT: one workgroup per CU (LDS allows
-// no more) walks the blocks blockIdx.x, + gridDim.x, ... -- the same blocks the hardware would have handed that XCD one by
-// one (bid & 7 is preserved) -- without a workgroup launch, LDS allocation and wave start between them (-1.6 % fast,
-// -2.5 % auto at C2).  Causal launches keep one workgroup per block: their blocks differ in length, the hardware's
-// hand-out (heaviest first) balances them; a static stride over the same order was 6 % slower, and persistent workgroups
-// taking balanced PAIRS of blocks (qb = j and nqb - 1 - j of one head) 3-5 % slower in fast and 10 % in auto mode.
 // CHECK: QATTN_PRECISION_AUTO -- one-term passes carry the two peakedness statistics (R and the effective key count) and end
 // with the vote / rescue / redo logic; the FAST launches instantiate neither.
+// One launch covers every query block of every head, and launches are PERSISTENT: one workgroup per CU (LDS allows no more),
+// no workgroup launch, LDS allocation and wave start between blocks (-1.6 % fast, -2.5 % auto at C2 against one workgroup
+// per block).  Non-causal: blocks are equal, the workgroups walk them with a fixed stride (blockIdx.x, + gridDim.x, ...: the
+// blocks the hardware would have handed that XCD one by one, bid & 7 is preserved).  Causal: blocks differ 16 : 1, so with a
+// scheduler state in the workspace (SchedState, qattn_attn.h) a workgroup starts on block blockIdx.x and draws its next blocks
+// from its XCD label's counter -- the order in which the hardware would have handed that XCD its workgroups: a head's K/V stay
+// in that XCD's L2 and the order is longest-processing-time first; a workgroup whose counter has run dry takes blocks of the
+// other XCDs (S = 8192: -4 %, S = 16384: -2...3 % against one workgroup per block; S = 4096: equal).  A static stride over that
+// order was 6 % slower and balanced pairs of blocks 3-10 % slower in round 2.  Without the state (a caller without a
+// workspace) causal launches use one workgroup per block.
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false, bool CHECK = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if constexpr (CAUSAL) {
-        run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p_arg, smem, blockIdx.x);
-    } else {
-        const int nblocks = p_arg.total_blocks;
-        for (int bid = blockIdx.x; bid < nblocks; bid += gridDim.x) {
-            // the parameters are re-read from the kernel-argument segment every block (scalar loads): left to the compiler they
-            // are hoisted out of this loop, stay live across whole blocks and push the scalar file into spilling
+    // two words behind the waves' vote words carry a block number / queue item from thread 0 to the workgroup
+    volatile unsigned* bcast = reinterpret_cast<volatile unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D) + 8;
 #if defined(__HIP_DEVICE_COMPILE__)
-            typedef const __attribute__((address_space(4))) AttnParams* KernargPtr;
-            KernargPtr pk = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();   // AttnParams is the kernel's only argument
-            asm volatile("" : "+s"(pk));
-            const AttnParams& p = *(const AttnParams*)pk;
+    // the parameters are re-read from the kernel-argument segment every block (scalar loads): left to the compiler they
+    // are hoisted out of the block loop, stay live across whole blocks and push the scalar file into spilling
+    typedef const __attribute__((address_space(4))) AttnParams* KernargPtr;
+#define QATTN_PARAMS()                                                                                   \
+    KernargPtr pk_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr(); /* AttnParams is the only argument */ \
+    asm volatile("" : "+s"(pk_));                                                                        \
+    const AttnParams& p = *(const AttnParams*)pk_
 #else
-            const AttnParams& p = p_arg;
+#define QATTN_PARAMS() const AttnParams& p = p_arg
 #endif
-            run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p, smem, bid);
-            if (bid + (int)gridDim.x < nblocks) __syncthreads();   // every wave has left the ring and the Q slots before the next block fills them
+    const bool dynamic = p_arg.sched != nullptr;   // launch-uniform
+    // The thread index is rebuilt every round from the wave's number (a scalar) and v_mbcnt (volatile: not hoisted): threadIdx.x
+    // kept live across the block loop costs a vector register the tightest instantiations do not have (one spilled dword).
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int bid = blockIdx.x;
+    for (;;) {
+        int tid;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
+        tid |= wave_s << 6;
+        asm volatile("" : "+v"(tid));
+        unsigned resc;
+        {
+            QATTN_PARAMS();
+            resc = run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p, smem, bid, tid);
         }
+        if constexpr (CHECK && !TOKEN && NW == 8) {
+            // a few peaked 32-row groups: on the spot, while the head's K / V are in this XCD's L2 (every wave is past the vote
+            // barrier, hence done with the K/V ring).  The next block is drawn afterwards: a block reserved before the rescue would
+            // wait for it while other workgroups idle (+16 us at the end of a C3 launch).
+            if (resc != 0u) {
+                QATTN_PARAMS();
+                asm volatile("" : "+v"(tid));
+                rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16>(p, smem, tid, bid, resc);
+            }
+        }
+        QATTN_PARAMS();
+        int next = -1;
+        if (dynamic) {
+            // (the atomic's latency hides behind the other waves' epilogues: wave 0 is one of the first to finish)
+            if (tid == 0) {
+                const int nq = p.sched_nq;
+                bcast[0] = (unsigned)sched_next_block(p.sched, nq, (int)blockIdx.x & (nq - 1), p.total_blocks / nq, (int)gridDim.x / nq);
+            }
+            __syncthreads();   // also: every wave has left the ring and the Q slots before the next block fills them
+            next = __builtin_amdgcn_readfirstlane((int)bcast[0]);
+        } else if (!CAUSAL && bid + (int)gridDim.x < p.total_blocks) {
+            next = bid + (int)gridDim.x;
+            __syncthreads();
+        }
+        if (next < 0) break;
+        bid = next;
     }
+#undef QATTN_PARAMS
 }
 
 template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16, bool CHECK>
@@ -906,10 +997,26 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     // one persistent workgroup per CU (a multiple of 8 keeps every workgroup's blocks on one XCD: blocks b and b + grid share
     // b & 7; xcd_remap is only set on an 8-XCD device, qattn_api.hip); fewer blocks than CUs: one each
     const int cus = p.xcd_remap ? cu_count() & ~7 : cu_count();
-    const int grid = (!CAUSAL && p.persistent && cus >= 8 && p.total_blocks > cus) ? cus : p.total_blocks;
+    const bool persistent = p.persistent && cus >= 8 && p.total_blocks > cus;
+    int grid = persistent && (!CAUSAL || p.sched) ? cus : p.total_blocks;
+    if (p.sched && persistent && CAUSAL) {
+        // dynamic hand-out: per-XCD-label counters, zeroed every call (a memset node under graph capture)
+        p.sched_nq = p.xcd_remap ? 8 : 1;
+        if (hipMemsetAsync(p.sched, 0, sizeof(SchedState), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+    } else {
+        p.sched = nullptr;
+    }
     size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
+#endif
+#ifdef QATTN_DEV
+    if (CHECK && !CAUSAL && BYTE && NW == 8 && getenv("QATTN_ABL_NONEFF")) {   // dev: the AUTO kernel without the effective-key-count MFMA
+        auto kern0 = attn_fwd_kernel_v2<D, NW, FMT, FMT, false, TOKEN, true, 512, Q16, CHECK>;
+        (void)hipFuncSetAttribute((const void*)kern0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern0, dim3(grid), dim3(NW * 64), lds, st, p);
+        return QATTN_OK;
+    }
 #endif
     auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 0, Q16, CHECK>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
@@ -929,7 +1036,7 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     // (at unit score variance: the blocks whose first row sees fewer than kTwoTermKeys keys)
     p.n_two = p.precision == QATTN_PRECISION_ACCURATE ? p.nqb : 0;
 #ifdef QATTN_DEV
-    if (p.dbg >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
+    if ((p.dbg & 0xffff) >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
         const int grid = p.B * p.Hq * p.nqb;
         const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords;

@@ -333,10 +333,10 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     }
     constexpr float SHIFT = BYTE ? kPShiftByte : kPShift;
     if (p.peak_r0 > 0.0f && !two && !only_flagged) {
-        // one-term launch: R = l' / p'_max is the inverse of the row's largest softmax weight; a peaked row flags its group
-        // ... and l'^2 / sum P'^2 its effective key count (kPeakNeff, qattn_attn.h)
-        const float neff_min = p.peak_neff * (BYTE ? 1.0f / kNeffByteRatio : 1.0f);
-        const bool peaked = qrow < p.Sq && (l_tot * __builtin_amdgcn_exp2f(-(SHIFT + (m_true - m_run) * c)) < p.peak_r0 || l_tot * l_tot < neff_min * l2_tot);
+        // one-term launch: a peaked row (row_is_peaked, qattn_attn.h: R = l' / p'_max and the effective key count) flags its group
+        const float r_inv_pmax = __builtin_amdgcn_exp2f(-(SHIFT + (m_true - m_run) * c));
+        const bool peaked = qrow < p.Sq && (neff ? row_is_peaked<BYTE, true>(p, l_tot, l2_tot, r_inv_pmax, m_true == m_run)
+                                                 : row_is_peaked<BYTE, false>(p, l_tot, l2_tot, r_inv_pmax, false));
         if (__any(peaked) && lane == 0 && q0 < p.Sq) *flag = 1u;
     }
     const float sv = p.sv ? p.sv[kv_head] : 1.0f;

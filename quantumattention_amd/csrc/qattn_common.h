@@ -189,13 +189,44 @@ __host__ __device__ inline int vblock_exponent(unsigned amax_bits, int out_fmt) 
     return e < -126 ? -126 : e > 126 ? 126 : e;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Whole-wave reductions and lane exchanges WITHOUT a lane-index register.  __shfl_xor / __shfl go through ds_bpermute with an
+// address computed from the lane id; in the persistent attention kernels those six or eight loop-invariant address registers
+// are hoisted to the top of the block loop, stay live through the hand-scheduled sweeps and -- the kernels sit at the
+// 256-register limit -- get spilled.  DPP row operations, ds_swizzle with an immediate pattern and v_permlane32_swap need none.
+//   partner within a quad / 8 lanes / 16 lanes: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+//   partner 16 lanes away: ds_swizzle bit mode, xor mask 16;  partner 32 lanes away: v_permlane32_swap
+// ---------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned swizzle_xor16(unsigned x) { return (unsigned)__builtin_amdgcn_ds_swizzle((int)x, (16 << 10) | 0x1f); }
+template <typename Op>
+__device__ __forceinline__ unsigned wave_allreduce_u32(unsigned x, Op op) {   // the same value in all 64 lanes
+    x = op(x, dpp_u32<0xB1>(x));    // quad_perm [1,0,3,2]
+    x = op(x, dpp_u32<0x4E>(x));    // quad_perm [2,3,0,1]
+    x = op(x, dpp_u32<0x141>(x));   // row_half_mirror: lane i <-> 7 - i of its 8
+    x = op(x, dpp_u32<0x140>(x));   // row_mirror:      lane i <-> 15 - i of its 16
+    x = op(x, swizzle_xor16(x));
+    const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return op(sw[0], sw[1]);
+}
+__device__ __forceinline__ float wave_allsum(float x) {
+    return __uint_as_float(wave_allreduce_u32(__float_as_uint(x), [](unsigned a, unsigned b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); }));
+}
+__device__ __forceinline__ unsigned wave_allmax_u32(unsigned x) {
+    return wave_allreduce_u32(x, [](unsigned a, unsigned b) { return a > b ? a : b; });
+}
+// every lane q reads lane q & 15 (the 16x16 MFMA's row sums live in lanes 0..15)
+__device__ __forceinline__ float bcast_low16(float x) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);   // [0]: lanes 32.. <- lanes 0..31
+    return __int_as_float(__builtin_amdgcn_ds_swizzle((int)sw[0], 0x0f));   // bit mode, and mask 0x0f: lane i <- lane i & 15 of its 32
+}
+
 // the maximum of a head's per-block abs-max words, the same value in every lane
 __device__ inline unsigned max_partials(const unsigned* part, int n, int lane) {
     unsigned m = 0u;
     for (int i = lane; i < n; i += 64) m = max(m, part[i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    return m;
+    return wave_allmax_u32(m);
 }
 
 // q/k/v pre-pass launcher shared by qattn_quant_qkv_fp8 and the fused step entry (qattn_api.hip).  `ws` holds the per-block

@@ -28,7 +28,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert getattr(L, n) is not None, n
     lib = _native.lib()
-    assert lib.qattn_abi_version() == _native.ABI_VERSION == 4
+    assert lib.qattn_abi_version() == _native.ABI_VERSION == 5
 
 
 def test_abi_size_queries_and_error_codes_need_no_gpu():
@@ -39,8 +39,9 @@ def test_abi_size_queries_and_error_codes_need_no_gpu():
     assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_HEAD) == 4 * 32 * 4
     assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_TOKEN) == 0
     assert L.qattn_quant_qkv_workspace_bytes(4, 32, 8) == 4 * 256 * ((128 + 64) + 160)   # per-block abs-max words of q, k, v | per-block sums of squares of q and k
-    assert L.qattn_attention_workspace_bytes(4, 32, 4096) == 4 * 32 * 128 * 4          # one word per 32-row query group
-    assert L.qattn_fp8_quant_attention_workspace_bytes(4, 32, 8, 4096) == 4 * 256 * ((128 + 64) + 160) + 4 * 32 * 128 * 4   # both parts multiples of 16
+    attn_ws = 32 + 4 * 32 * 128 * 4      # block hand-out counters of a causal launch | one word per 32-row query group
+    assert L.qattn_attention_workspace_bytes(4, 32, 4096) == attn_ws
+    assert L.qattn_fp8_quant_attention_workspace_bytes(4, 32, 8, 4096) == 4 * 256 * ((128 + 64) + 160) + attn_ws   # both parts multiples of 16
     assert L.qattn_lse_row_stride(1000, _native.LSE_NATURAL) == 1000
     assert L.qattn_lse_row_stride(1001, _native.LSE_REFERENCE) == 1004                 # row padded to 16 bytes (tk/attention.py:439)
     for code in range(0, -7, -1):

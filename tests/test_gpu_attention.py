@@ -330,15 +330,16 @@ def test_c_abi_error_codes_instead_of_exceptions():
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     f0 = ctypes.c_float(0.0)
 
-    wsb = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    need = L.qattn_attention_workspace_bytes(1, 2, 64)
+    wsb = torch.zeros(need, dtype=torch.uint8, device="cuda")
 
-    def attn(D=128, Hq=2, Hkv=2, qk=0, vf=0, of=2, mode=0, q=q8, precision=0, lse_layout=0, ws=wsb, ws_bytes=64):
+    def attn(D=128, Hq=2, Hkv=2, qk=0, vf=0, of=2, mode=0, q=q8, precision=0, lse_layout=0, ws=wsb, ws_bytes=need):
         return L.qattn_fp8_attention_forward(P(q) if q is not None else None, P(q8), P(q8), P(out), None, P(sc), P(sc), None,
                                              1, Hq, Hkv, 64, 64, D, qk, vf, of, mode, 0, f0, precision, lse_layout,
                                              P(ws) if ws is not None else None, ctypes.c_size_t(ws_bytes), None)
 
     assert attn() == 0 and attn(precision=1, ws=None, ws_bytes=0) == 0 and attn(precision=2, ws=None, ws_bytes=0) == 0
-    assert attn(ws=None, ws_bytes=0) == -4 and attn(ws_bytes=8) == -4       # QATTN_PRECISION_AUTO needs its flag words (2 heads x 2 groups)
+    assert attn(ws=None, ws_bytes=0) == -4 and attn(ws_bytes=need - 8) == -4       # QATTN_PRECISION_AUTO needs its workspace in full
     assert attn(precision=3) == -1 and attn(lse_layout=2) == -1
     assert attn(D=96) == -2 and L.qattn_strerror(-2) is not None       # head_dim not in {64,128,256} (nn.py:45-49)
     assert attn(Hq=3, Hkv=2) == -2                                     # Hq % Hkv != 0

@@ -8,6 +8,7 @@ its own operands, and each (library, precision, path) variant is timed with HIP 
   paths: fused = qattn_fp8_quant_attention_forward (the bench step), attn = qattn_fp8_attention_forward on pre-quantised
          operands, quant = qattn_quant_qkv_fp8.
   default libraries: new=quantumattention_amd/libqattn_hip.so r2=tools/bin/libqattn_r2.so (if present)
+  name=path@VAR=VAL[@VAR2=VAL2]: environment set around that variant's calls (dev library switches that are read per call)
 Prints median / min ms per variant and the ratio to the first library's variant of the same (precision, path).
 """
 import argparse
@@ -96,7 +97,12 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies q (score spread)")
     ap.add_argument("--settle", type=float, default=0.5)
     a = ap.parse_args()
-    libs = [x.split("=", 1) for x in a.libs]
+    libs, envs = [], {}
+    for x in a.libs:
+        n, rest = x.split("=", 1)
+        parts = rest.split("@")
+        libs.append([n, parts[0]])
+        envs[n] = dict(e.split("=", 1) for e in parts[1:])
     if not libs:
         libs = [["new", os.path.join(ROOT, "quantumattention_amd", "libqattn_hip.so")]]
         if os.path.exists(os.path.join(ROOT, "tools", "bin", "libqattn_r2.so")):
@@ -106,12 +112,20 @@ def main():
     q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
     if a.scale != 1.0:
         q = (q.float() * a.scale).to(torch.bfloat16)
-    vs = [Variant(n, load(p), q, k, v, a.causal, FMT[a.fp8]) for n, p in libs]
+    loaded = {}
+    vs = [Variant(n, loaded.setdefault(p, load(p)), q, k, v, a.causal, FMT[a.fp8]) for n, p in libs]
     jobs = []
     for path in a.paths.split(","):
         for prec in (a.prec.split(",") if path != "quant" else ["-"]):
             for x in vs:
-                fn = x.quant if path == "quant" else (lambda x=x, p=PREC[prec], path=path: getattr(x, path)(p))
+                raw = x.quant if path == "quant" else (lambda x=x, p=PREC[prec], path=path: getattr(x, path)(p))
+
+                def fn(raw=raw, env=envs.get(x.name, {})):
+                    for k_, v_ in env.items():
+                        os.environ[k_] = v_
+                    raw()
+                    for k_ in env:
+                        del os.environ[k_]
                 jobs.append((f"{path:5s} {prec:8s} {x.name}", (path, prec), fn))
     t_end = time.time() + a.settle          # settle the clocks under load (the chip idles at 102 MHz)
     while time.time() < t_end:
