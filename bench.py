@@ -21,7 +21,14 @@ The JSON line also carries
                   on a bounded sample of the same workload;
   quant_prepass_ms / quant_prepass_in_step_ms -- the separate qattn_quant_qkv_fp8 call, and the pre-pass inside the step (step
                   minus attention), each against 603.98 MB of algorithmic bytes at C2;
-  sustained_ms_per_step, c3_*, c5_* -- a >= 2 s back-to-back run and the causal / long-context configs (N=1 only).
+  sustained_ms_per_step, c3_*, c5_* -- a >= 2 s back-to-back run and the causal / long-context configs (N=1 only);
+  under_load / attn_under_load / joules_per_step -- socket power, cap and shader clock (rocm-smi) while the step, resp. the
+                  attention launch alone, keeps the queue full;
+  reference_bench_shape -- the reference's own benchmark grid B16 H16 S8192, D in {64,128,256}, causal and not
+                  (tests/test_interface.py:95-102,141-156), through the same fp8_attn_func step;
+  accuracy     -- max-abs / rmse of the step's output on a head slice of C2, C3 and C5 against fp64 SDPA (torch, on the GPU) of the
+                  same quantised q, k with the ORIGINAL 16-bit V (the reference's own semantics: it keeps V and P in 16 bit) and
+                  with this build's quantised V.
 Timing protocol: --settle seconds (default 0.3) of untimed steps bring the idle GPU (sclk ~100 MHz) to its sustained,
 power-capped state (tools/time_ramp.py: the first 20 steps after idle run 16 % slower than the next thousands), then the W
 warm-up steps, a barrier + synchronize, EXACTLY K timed steps, a barrier + synchronize.  `settle_steps` reports how many
@@ -113,6 +120,57 @@ def cpu_baseline(args, q, k, v):
                   f"torch {torch.__version__} CPU bf16 SDPA on de-quantised q,k (ops.py:64-95)",
         "seconds": best,
     }
+
+
+def smi_start():
+    try:
+        return subprocess.Popen(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], stdout=subprocess.PIPE,
+                                stderr=subprocess.DEVNULL, text=True)
+    except Exception:
+        return None
+
+
+def smi_read(smi, source):
+    import re
+
+    try:
+        txt = smi.communicate(timeout=20)[0]
+    except Exception:
+        return None
+    grab = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, txt))
+    return {"socket_power_w": grab(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)"),
+            "power_cap_w": grab(r"Max Graphics Package Power \(W\): ([0-9.]+)"),
+            "sclk_mhz": grab(r"sclk clock level: \S+ \(([0-9.]+)Mhz\)"), "source": source}
+
+
+def accuracy_vs_16bit_v(torch, _native, q, k, v, out, causal, fp8, rows):
+    """max-abs / rmse of out[0, 0, rows] against fp64 SDPA (torch, on the GPU) of the library's own quantised q, k of that head
+    with (a) the original 16-bit V -- what the reference computes, it never quantises V -- and (b) V quantised per head."""
+    fp8_dtype = _native.FP8_DTYPE[fp8]
+    D = q.shape[-1]
+    q8, sq = _native.quant_fp8(q[:1, :1].contiguous(), fp8_dtype=fp8_dtype)
+    k8, sk = _native.quant_fp8(k[:1, :1].contiguous(), fp8_dtype=fp8_dtype)
+    v8, sv = _native.quant_fp8(v[:1, :1].contiguous(), fp8_dtype=fp8_dtype)
+    qd = q8[0, 0].float().double() * float(sq[0, 0])
+    kd = k8[0, 0].float().double() * float(sk[0, 0])
+    vd16 = v[0, 0].double()
+    vd8 = v8[0, 0].float().double() * float(sv[0, 0])
+    got = out[0, 0].double()
+    worst = {"max_abs_vs_16bitV": 0.0, "max_abs_vs_quantisedV": 0.0}
+    se, n = 0.0, 0
+    for r0 in rows:
+        r1 = min(r0 + 1024, q.shape[2])
+        sc = (qd[r0:r1] @ kd.T) / D ** 0.5
+        if causal:
+            sc = sc.masked_fill(torch.arange(k.shape[2], device=sc.device)[None, :] > torch.arange(r0, r1, device=sc.device)[:, None], float("-inf"))
+        pm = torch.softmax(sc, dim=1)
+        d16 = (got[r0:r1] - pm @ vd16).abs()
+        worst["max_abs_vs_16bitV"] = max(worst["max_abs_vs_16bitV"], float(d16.max()))
+        worst["max_abs_vs_quantisedV"] = max(worst["max_abs_vs_quantisedV"], float((got[r0:r1] - pm @ vd8).abs().max()))
+        se += float((d16 ** 2).sum()); n += d16.numel()
+    worst["rmse_vs_16bitV"] = (se / n) ** 0.5
+    worst["slice"] = f"batch 0, head 0, rows {[(r, min(r + 1024, q.shape[2])) for r in rows]}"
+    return worst
 
 
 def kernel_label(D, fp8, causal, fused_q):
@@ -318,14 +376,9 @@ def run_rank(args):
                 # wait inside the run: the events are read after the last window)
                 evs, t_end = [torch.cuda.Event(enable_timing=True)], time.perf_counter() + 2.0
                 evs[0].record()
-                smi = None
-                try:   # socket power and shader clock while the queue is full (read-only rocm-smi, a child process: ~0.5 s)
-                    for _ in range(400):
-                        step()
-                    smi = subprocess.Popen(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], stdout=subprocess.PIPE,
-                                           stderr=subprocess.DEVNULL, text=True)
-                except Exception:
-                    smi = None
+                for _ in range(400):
+                    step()
+                smi = smi_start()   # socket power and shader clock while the queue is full (read-only rocm-smi, a child process: ~0.5 s)
                 while time.perf_counter() < t_end or len(evs) < 6 or (smi is not None and smi.poll() is None and time.perf_counter() < t_end + 10):
                     for _ in range(20):
                         step()
@@ -338,16 +391,34 @@ def run_rank(args):
                 line["sustained_ms_per_step"] = windows[len(windows) // 2]
                 line["sustained_windows"] = len(windows)
                 if smi is not None:
-                    try:
-                        txt = smi.communicate(timeout=20)[0]
-                        import re
-                        grab = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, txt))
-                        line["under_load"] = {"socket_power_w": grab(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)"),
-                                              "power_cap_w": grab(r"Max Graphics Package Power \(W\): ([0-9.]+)"),
-                                              "sclk_mhz": grab(r"sclk clock level: \S+ \(([0-9.]+)Mhz\)"),
-                                              "source": "rocm-smi, sampled while the sustained run keeps the queue full"}
-                    except Exception:
-                        pass
+                    line["under_load"] = smi_read(smi, "rocm-smi, sampled while the sustained run of the whole step keeps the queue full")
+                    if line["under_load"] and line["under_load"].get("socket_power_w"):
+                        line["joules_per_step"] = line["under_load"]["socket_power_w"] * line["sustained_ms_per_step"] * 1e-3
+                # the same sample with the ATTENTION launch alone in the queue (pre-quantised operands): the kernel the roofline is about
+                q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q, k, v, fp8_dtype=fp8_dtype)
+                attn_alone = lambda: _native.fp8_attention_forward(q8, kf, vf, sq, sk, sv, Hkv=H, Skv=S, out_dtype=torch.bfloat16,
+                                                                   is_causal=args.causal, precision=args.precision)
+                t_end, smi, n_calls = time.perf_counter() + 1.5, None, 0
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(600):
+                    attn_alone()
+                e0.record()
+                while time.perf_counter() < t_end or (smi is not None and smi.poll() is None and time.perf_counter() < t_end + 10):
+                    if smi is None:
+                        smi = smi_start()
+                        if smi is None:
+                            break
+                    for _ in range(50):
+                        attn_alone()
+                    n_calls += 50
+                    torch.cuda.synchronize() if n_calls % 400 == 0 else None
+                e1.record()
+                torch.cuda.synchronize()
+                if smi is not None and n_calls:
+                    line["attn_under_load"] = smi_read(smi, "rocm-smi, sampled while the attention launch alone (pre-quantised operands) keeps the queue full")
+                    if line["attn_under_load"]:
+                        line["attn_under_load"]["ms_per_launch"] = e0.elapsed_time(e1) / n_calls
+                del q8, kf, vf
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
             def extra(Bx, Hx, Sx, causal, fp8, n):
                 qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
@@ -361,6 +432,35 @@ def run_rank(args):
             if (B, H, S, D) == (4, 32, 4096, 128) and not args.causal:
                 line["c3_causal_B4_H32_S4096"] = extra(4, 32, 4096, True, "e4m3", 20)
                 line["c5_causal_e5m2_B4_H40_S16384"] = extra(4, 40, 16384, True, "e5m2", 5)
+                # the reference's own benchmark grid (tests/test_interface.py:95-102,141-156): B16 H16 S8192, D in {64,128,256}
+                ref_grid = {}
+                for Dx in (64, 128, 256):
+                    for causal in (False, True):
+                        qx, kx, vx = (torch.randn(16, 16, 8192, Dx, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+                        fn = lambda: qa.fp8_attn_func(qx, kx, vx, is_causal=causal)
+                        with qa.config.patch({"attention.fp8_format": "e4m3", "attention.precision": args.precision}):
+                            for _ in range(10):
+                                fn()
+                            ms = event_time(fn, 5)
+                            ams = attn_in_step(fn, 3)
+                        fl = flops(16, 16, 8192, 8192, Dx, causal)
+                        ref_grid[f"D{Dx}_{'causal' if causal else 'full'}"] = {
+                            "ms_per_step": ms, "attn_kernel_ms": ams, "step_TFLOPs": fl / (ms * 1e-3) / 1e12,
+                            "attn_frac_of_peak": None if not ams else fl / (ams * 1e-3) / 1e12 / FP8_PEAK_TFLOPS}
+                        del qx, kx, vx
+                line["reference_bench_shape"] = {"shape": "B16 H16 S8192, bf16 in/out, e4m3, head-wise (tests/test_interface.py:95-102)", **ref_grid}
+                # distance to the reference's own semantics (V and P stay 16-bit there), per config, on a head slice
+                acc = {}
+                with qa.config.patch({"attention.fp8_format": "e4m3", "attention.precision": args.precision}):
+                    acc["c2"] = accuracy_vs_16bit_v(torch, _native, q, k, v, qa.fp8_attn_func(q, k, v, is_causal=False), False, "e4m3", [0, 3072])
+                    acc["c3"] = accuracy_vs_16bit_v(torch, _native, q, k, v, qa.fp8_attn_func(q, k, v, is_causal=True), True, "e4m3", [0, 1024, 3072])
+                qx, kx, vx = (torch.randn(1, 2, 16384, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+                with qa.config.patch({"attention.fp8_format": "e5m2", "attention.precision": args.precision}):
+                    acc["c5_shape_B1_H2"] = accuracy_vs_16bit_v(torch, _native, qx, kx, vx, qa.fp8_attn_func(qx, kx, vx, is_causal=True), True, "e5m2", [0, 8192, 15360])
+                del qx, kx, vx
+                acc["note"] = ("fp64 SDPA (torch, GPU) of the library's quantised q, k; the 16-bit-V column is the reference's semantics "
+                               "(tk/attention.py:286,318), the quantised-V column uses one scale per head (the fused step scales V per 64-key chunk)")
+                line["accuracy"] = acc
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, q, k, v)
         print(json.dumps(line), flush=True)

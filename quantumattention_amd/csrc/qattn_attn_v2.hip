@@ -87,6 +87,9 @@ struct WaveState {
     v8i qreg[2];   // QREG kernels: the wave's Q^T fragments (both k-steps) held in registers instead of re-read from LDS
     v8i ones;      // BYTE mode: the all-ones A operand of that MFMA, kept opaque so it is not re-materialised every iteration
     float c;       // scale_q*scale_k*sm_scale*log2(e)
+    // two values that change only with m_run (fix-up branch), kept instead of re-derived every iteration (2 + 2 VALU of ~87):
+    float mcv;     // the additive constant of the exponent / byte formula for the current m_run (full_step: mc)
+    float lim;     // m_run + thr / c: a row's chunk max above it means P' could overflow -> fix-up
     int vsx;       // block-scaled V: E8M0 byte of the V chunk the current iteration's PV products read (127 = 2^0)
 #ifdef QATTN_DEV
     unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
@@ -246,26 +249,37 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     // (byte mode carries the 1/65535 of v_cvt_pknorm_u16_f32's [0,1] -> [0,65535] map in both constants)
     constexpr float U16 = (ABL & 32) ? 1.0f : 1.0f / 65535.0f;
     const float cx = BYTE ? (8.0f * U16) * c : c;
-    const float mc = BYTE ? __builtin_fmaf((-8.0f * U16) * st.m_run, c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - st.m_run * c;
+    const float mc = st.mcv;
     float acc[4], acc2[4];
 
     // slot 0: O0 += V0.P(t-2)            reads: V2            VALU: max over tile 0
     st.o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[0], pp, st.o[0], st.vsx);
     if (TWO) st.o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[0], ppl, st.o[0], st.vsx);
     v8i fc = LDSF(vprev + (2 << 11));
-    // (v_max3_f32 through asm: on MFMA results the compiler otherwise adds a canonicalising v_max_f32 x, x, x per chain)
-    float mx = max3_raw(sc0[0], sc0[1], sc0[2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = max3_raw(mx, sc0[r], sc0[r + 1]);
+    // (v_max3_f32 through asm: on MFMA results the compiler otherwise adds a canonicalising v_max_f32 x, x, x per chain.  Three
+    // interleaved chains: hipcc pads wait states between an asm statement and a VALU that reads its output unless two other
+    // instructions sit in between, so a single chain of dependent asm v_max3 carried an s_nop per link -- eight issue slots per iteration)
+    float mxa = max3_raw(sc0[0], sc0[1], sc0[2]);
+    float mxb = max3_raw(sc0[3], sc0[4], sc0[5]);
+    float mxc = max3_raw(sc0[6], sc0[7], sc0[8]);
+    mxa = max3_raw(mxa, sc0[9], sc0[10]);
+    mxb = max3_raw(mxb, sc0[11], sc0[12]);
+    mxc = max3_raw(mxc, sc0[13], sc0[14]);
     QATTN_SLOT_FENCE();
     // slot 1: O1 += V1.P(t-2)            reads: V3            VALU: max over tile 1, group 0
     st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], pp, st.o[1], st.vsx);
     if (TWO) st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], ppl, st.o[1], st.vsx);
     v8i fd = LDSF(vprev + (3 << 11));
-    mx = max3_raw(mx, sc0[15], sc1[0]);
-#pragma unroll
-    for (int r = 1; r < 15; r += 2) mx = max3_raw(mx, sc1[r], sc1[r + 1]);
-    mx = max3_raw(mx, sc1[15], sc1[15]);
+    mxa = max3_raw(mxa, sc0[15], sc1[0]);
+    mxb = max3_raw(mxb, sc1[1], sc1[2]);
+    mxc = max3_raw(mxc, sc1[3], sc1[4]);
+    mxa = max3_raw(mxa, sc1[5], sc1[6]);
+    mxb = max3_raw(mxb, sc1[7], sc1[8]);
+    mxc = max3_raw(mxc, sc1[9], sc1[10]);
+    mxa = max3_raw(mxa, sc1[11], sc1[12]);
+    mxb = max3_raw(mxb, sc1[13], sc1[14]);
+    mxc = max3_raw(mxc, sc1[15], sc1[15]);
+    float mx = max3_raw(mxa, mxb, mxc);
     QATTN_SM_GROUP(true, sc0, 0, mc, 0, pp[0]);
     QATTN_SLOT_FENCE();
     // slot 2: O2 += V2.P(t-2)            reads: Q k-step 0, K(tile 0, k-step 0)      VALU: group 1
@@ -317,17 +331,19 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     sn1 = mfma_f8<QK_FMT, QK_FMT>(kd, qg, sn1);
     QATTN_SM_GROUP(false, sc1, 3, mc, 7, pc[6]);
     {
+        // (v_max3 through asm: fmaxf on these would be preceded by two canonicalising v_max_f32 x, x, x)
+        // (the two chains meet here; m_true takes the exchanged halves directly: two independent asm statements, no pad)
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        if (!TWO) st.m_true = max3_raw(st.m_true, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        mx = max3_raw(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
     }
-    if (!TWO) st.m_true = fmaxf(st.m_true, mx);
     float ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     float ls2 = (BYTE || !NEFF) ? 0.0f : (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]);
     QATTN_SLOT_FENCE();
     QATTN2_STAMP(2);
     // rare fix-up: some row's max grew by more than the threshold (always on the first chunk: m_run = -1e30):
     // rescale everything accumulated so far (O and the row sum include chunk t-2) and redo this chunk's exponentials
-    if (__builtin_expect(__any((mx - st.m_run) * c > THR) != 0, 0)) {
+    if (__builtin_expect(__any(mx > st.lim) != 0, 0)) {   // (mx - m_run) c > THR
         const float m_new = fmaxf(st.m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((st.m_run - m_new) * c);
 #pragma unroll
@@ -345,6 +361,8 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
         }
         st.m_run = m_new;
         const float mc2 = BYTE ? __builtin_fmaf((-8.0f * U16) * m_new, c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - m_new * c;
+        st.mcv = mc2;
+        st.lim = m_new + THR / c;
         QATTN_SM_GROUP(true, sc0, 0, mc2, 0, 0);
 #pragma unroll
         for (int j = 1; j < 4; j++) QATTN_SM_GROUP(false, sc0, j, mc2, j, 0);
@@ -439,6 +457,10 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         slot_cur = slot_cur + STAGE == kStagesV2 * STAGE ? 0u : slot_cur + STAGE;
     };
     auto do_stage = [&](int) {};
+    // (VS) the scale byte of V(t - 1), requested during iteration t: a running LDS address (one scalar add per iteration; the table
+    // holds nchunks <= kVxWords live entries, a longer head has no chunk scales and re-reads entry 0 = 2^0)
+    const unsigned* vx_next = vx;
+    const int vx_step = (VS && p.vexp != nullptr) ? 4 : 0;
     // ragged_tag: may chunk t - 1 (the one this iteration exponentiates) reach past the key range?  Only a head's last chunk can;
     // non-causal sweeps say so statically for all iterations but the last (prep_scores)
     auto full = [&](auto par_tag, int t, auto ragged_tag) __attribute__((always_inline)) {
@@ -451,7 +473,8 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         prep_scores<CAUSAL, TOKEN, RAGGED>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
         // (VS) iteration t + 1 multiplies V(t - 1): its scale byte is requested during iteration t (t = 1 runs on the initial 2^0: P = 0)
-        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF>(st, kbuf, vprev, kbuf + CH, qbuf, stage, VS ? vx + min(t - 1, kVxWords - 1) : nullptr);
+        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF>(st, kbuf, vprev, kbuf + CH, qbuf, stage, vx_next);
+        if constexpr (VS) vx_next = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(vx_next) + vx_step);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -593,6 +616,8 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     st.m_true = -1.0e30f;
     st.l_run = 0.0f;
     st.c = c;
+    st.mcv = 0.0f;       // (the first chunk always takes the fix-up branch, which sets both)
+    st.lim = -1.0e30f;
     st.vsx = 127;   // 2^0
 #ifdef QATTN_DEV
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
