@@ -191,6 +191,28 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
                                       int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same step for a caller that PRODUCES q / k / v itself and already knows per-head figures of them (the epilogue of its
+ * projection or RoPE kernel): the counterpart of what the reference gets from Inductor, which traces `_dynamically_quantize_fp8`
+ * into the caller's graph and fuses the abs-max reduction with whatever wrote q and k (nn.py:410-418).  Head-wise scales only.
+ *   amax_q / amax_k / amax_v  NULL, or fp32 [B,Hq] / [B,Hkv] / [B,Hkv]: max |x| over each head of the 16-bit tensor, exactly (the
+ *                             fp32 value of the largest 16-bit magnitude).  A tensor with a supplied abs-max takes no part in the
+ *                             abs-max launch; with all of them supplied (amax_v is not needed where V is block-scaled: D = 128,
+ *                             bf16, Skv <= 16384) the launch is skipped -- at B4 H32 S4096 D128 that is 0.05 of 0.64 ms.  The
+ *                             results are bit-identical to qattn_fp8_quant_attention_forward's.  A value LARGER than the true
+ *                             abs-max is safe (a coarser scale, no clipping) but no longer the reference's scale; a smaller one clips.
+ *   ssq_q / ssq_k             NULL, or fp32 [B,Hq] / [B,Hkv]: sum of x^2 over each head (both or neither).  Only read under
+ *                             QATTN_PRECISION_AUTO, where the pre-pass otherwise accumulates them for the score-spread estimate
+ *                             that picks a head's starting precision; without them (and without the abs-max pass over q and k)
+ *                             every head starts in one-term mode, as through the separate calls.
+ */
+int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8, void* k8,
+                                         void* v8, float* scale_q, float* scale_k, float* scale_v, const float* amax_q,
+                                         const float* amax_k, const float* amax_v, const float* ssq_q, const float* ssq_k, int B,
+                                         int Hq, int Hkv, int Sq, int Skv, int D, int fp8_fmt, int scale_mode, int numerics,
+                                         int is_causal, float sm_scale, int precision, void* workspace, size_t workspace_bytes,
+                                         void* stream);
+
+/*
  * 16-bit sibling path: the non-fp8 build of the same kernel (TK_ATTN_IS_FP8 undefined, tk/attention.py:212,238-240,
  * 289-313) behind `quantum_attn::attention_forward(query, key, value, scale=None, is_causal=False)`
  * (src/quantum_attn/ops.py:17-45).  q/out row-major [B,Hq,Sq,D] bf16 or fp16 (`fmt`); k16/v16 are the key/value

@@ -6,7 +6,8 @@ from typing import Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqattn_hip.so")
+# (QUANTUM_ATTN_LIBRARY: another build of the same library, e.g. a tuning variant from `build.py --variant=...`; development aid)
+LIB_PATH = os.environ.get("QUANTUM_ATTN_LIBRARY") or os.path.join(_HERE, "libqattn_hip.so")
 
 FMT_E4M3, FMT_E5M2, FMT_BF16, FMT_FP16 = 0, 1, 2, 3
 SCALE_HEAD, SCALE_TOKEN = 0, 1
@@ -30,7 +31,7 @@ EXPORTS = (
     "qattn_pack_fp8", "qattn_fp8_attention_forward",
     "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16", "qattn_fp8_quant_attention_forward",
     "qattn_attention_workspace_bytes", "qattn_lse_row_stride", "qattn_fp8_quant_attention_workspace_bytes",
-    "qattn_profile_attention", "qattn_last_attention_ms", "qattn_vblock_exponent",
+    "qattn_profile_attention", "qattn_last_attention_ms", "qattn_vblock_exponent", "qattn_fp8_quant_attention_forward_ex",
 )
 
 _lib = None
@@ -85,6 +86,9 @@ def lib() -> ctypes.CDLL:
     L.qattn_fp8_quant_attention_workspace_bytes.argtypes = [i, i, i, i]
     L.qattn_fp8_quant_attention_forward.restype = i
     L.qattn_fp8_quant_attention_forward.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp]
+    L.qattn_fp8_quant_attention_forward_ex.restype = i
+    L.qattn_fp8_quant_attention_forward_ex.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                       i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp]
     if L.qattn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libqattn_hip.so ABI {L.qattn_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = L
@@ -283,16 +287,33 @@ def attention_forward_16(q: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Te
     return (out, lse) if return_lse else out
 
 
+def _per_head(name, t, B, H, device):
+    """producer-side per-head figure: fp32 [B,H] on the tensors' device (qattn_fp8_quant_attention_forward_ex)"""
+    if t is None:
+        return None
+    _require(t.dtype == torch.float32 and t.device == device and tuple(t.shape) == (B, H), f"{name} must be float32 {(B, H)} on {device}")
+    return t.contiguous()
+
+
 def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, is_causal: bool, scaling: str = "head-wise",
                                 fp8_dtype=torch.float8_e4m3fn, numerics: str = "compiled", sm_scale: float = 0.0,
-                                precision: str = "auto") -> torch.Tensor:
+                                precision: str = "auto", amax_q: Optional[torch.Tensor] = None,
+                                amax_k: Optional[torch.Tensor] = None, amax_v: Optional[torch.Tensor] = None,
+                                ssq_q: Optional[torch.Tensor] = None, ssq_k: Optional[torch.Tensor] = None) -> torch.Tensor:
     """16-bit q, k, v -> attention output: the quant pre-pass and the attention launch(es) in ONE C call
-    (qattn_fp8_quant_attention_forward); the pre-pass skips Q where the attention kernel quantises it itself."""
+    (qattn_fp8_quant_attention_forward_ex); the pre-pass skips Q where the attention kernel quantises it itself.
+    amax_* / ssq_*: per-head abs-max / sum of squares a producer of q, k, v already has (head-wise scaling only): the
+    abs-max launch then skips those tensors, or is skipped."""
     B, Hq, Hkv, Sq, Skv, D = _check_qkv(q, k, v)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     L = lib()
     mode = _scale_mode(scaling)
     dev = q.device
+    given = [x is not None for x in (amax_q, amax_k, amax_v, ssq_q, ssq_k)]
+    _require(not any(given) or mode == SCALE_HEAD, "amax_* / ssq_* are per-head figures: head-wise scaling only")
+    _require((ssq_q is None) == (ssq_k is None), "ssq_q and ssq_k must be both provided or both not provided")
+    amax_q, ssq_q = _per_head("amax_q", amax_q, B, Hq, dev), _per_head("ssq_q", ssq_q, B, Hq, dev)
+    amax_k, amax_v, ssq_k = (_per_head(n, t, B, Hkv, dev) for n, t in (("amax_k", amax_k), ("amax_v", amax_v), ("ssq_k", ssq_k)))
     with torch.cuda.device(dev):
         out = torch.empty_like(q)
         q8 = torch.empty((B, Hq, Sq, D), dtype=torch.uint8, device=dev)
@@ -303,9 +324,10 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         sv = torch.empty((B, Hkv), dtype=torch.float32, device=dev)
         ws_bytes = L.qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        rc = L.qattn_fp8_quant_attention_forward(
+        rc = L.qattn_fp8_quant_attention_forward_ex(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
-            vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
+            vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), _ptr(amax_q), _ptr(amax_k), _ptr(amax_v), _ptr(ssq_q),
+            _ptr(ssq_k), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
             NUMERICS[numerics], int(is_causal), float(sm_scale), _precision(precision), ws.data_ptr(), ws_bytes, _stream(q))
-    _check(rc, "qattn_fp8_quant_attention_forward")
+    _check(rc, "qattn_fp8_quant_attention_forward_ex")
     return out

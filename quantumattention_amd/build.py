@@ -53,11 +53,17 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = False, dev: bool = False) -> str:
+def build(force: bool = False, save_temps: bool = False, verbose: bool = False, dev: bool = False, variant: str = "",
+          extra_defines=()) -> str:
     """Compile what is stale and link the library; returns its path.  save_temps: compile every unit with -save-temps into
-    BUILD_TEMPS instead (same flags, same code; the library is left alone) and return that directory."""
-    build_dir = BUILD_TEMPS if save_temps else BUILD + ("_dev" if dev else "")
+    BUILD_TEMPS instead (same flags, same code; the library is left alone) and return that directory.
+    variant / extra_defines (development): a library of its own, tools/bin/libqattn_<variant>.so, compiled with the given -D macros
+    (kernel tuning knobs) for A/B runs with tools/ab.py or tools/kstats.sh."""
+    build_dir = BUILD_TEMPS if save_temps else BUILD + ("_dev" if dev else "") + (f"_var_{variant}" if variant else "")
     lib = LIB.replace(".so", "_dev.so") if dev else LIB
+    if variant:
+        lib = os.path.join(os.path.dirname(HERE), "tools", "bin", f"libqattn_{variant}.so")
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
     os.makedirs(build_dir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -74,7 +80,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
                 text = "".join(f"#define {d}\n" for d in defines) + f'#include "{s}"\n'
                 if not os.path.exists(unit) or open(unit).read() != text:
                     open(unit, "w").write(text)
-            cmd = [hipcc] + FLAGS + (["-DQATTN_DEV"] if dev else []) + ["-c", unit, "-o", o]
+            cmd = [hipcc] + FLAGS + (["-DQATTN_DEV"] if dev else []) + [f"-D{d}" for d in extra_defines] + ["-c", unit, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)
@@ -92,4 +98,6 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True, dev="--dev" in sys.argv))
+    var = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True, dev="--dev" in sys.argv,
+                variant=var, extra_defines=[a[2:] for a in sys.argv if a.startswith("-D")]))

@@ -74,11 +74,12 @@ struct AttnCall {
     void* attn_ws;     // nullptr or the attention workspace of THIS call (attn_ws_sched / attn_ws_flags below)
     const unsigned* vexp;         // fused step with a block-scaled V (else nullptr)
     const float *ssq_q, *ssq_k;   // fused step, head-wise AUTO: the heads' partial sums of squares from the pre-pass (else nullptr)
-    int ssq_n;
+    int ssq_n, ssq_stride;        //   (caller-supplied sums: one entry per head, stride 1)
     const void* q16;   // fused step (else nullptr): bf16 Q, quantised in the kernel from q_amax_part; sq_out is written
-    const unsigned* q_amax_part;   // per-block abs-max words of every q head [B*Hq][kMomentSplits], ssq_n valid per head
+    const unsigned* q_amax_part;   // abs-max words of every q head: [B*Hq][amax_stride], amax_n valid per head
     float* sq_out;
     int q_numerics;
+    int amax_n, amax_stride;
 };
 
 // attention workspace = [SchedState of the hand-scheduled kernel's causal launches | one flag word per (b, h, 32-row group)]
@@ -124,7 +125,8 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.ssq_q = a.precision == QATTN_PRECISION_AUTO ? a.ssq_q : nullptr;   // (FAST: the caller vouches for flat rows)
     p.ssq_k = p.ssq_q ? a.ssq_k : nullptr;
     p.vexp = a.vexp;
-    p.ssq_n = a.ssq_n; p.ssq_stride = kMomentSplits;
+    p.ssq_n = a.ssq_n; p.ssq_stride = a.ssq_stride;
+    p.amax_n = a.amax_n; p.amax_stride = a.amax_stride; p.vexp_stride = kMomentSplits;
     p.var_mul = sm * sm / ((float)a.Sq * (float)a.Skv * (float)a.D);
     p.sched = (SchedState*)a.attn_ws;
     p.flags = a.attn_ws ? (unsigned*)((unsigned char*)a.attn_ws + attn_ws_sched_bytes(a.B, a.Hq, a.Sq)) : nullptr;
@@ -295,7 +297,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
     if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
     AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
-               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
+               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
     return attention_impl(a, (hipStream_t)stream, ds);
 }
@@ -306,11 +308,12 @@ extern "C" size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int H
     return (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16 + qattn_attention_workspace_bytes(B, Hq, Sq);
 }
 
-extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
-                                                 void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v, int B,
-                                                 int Hq, int Hkv, int Sq, int Skv, int D, int fp8_fmt, int scale_mode,
-                                                 int numerics, int is_causal, float sm_scale, int precision, void* workspace,
-                                                 size_t workspace_bytes, void* stream) {
+extern "C" int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
+                                                    void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v,
+                                                    const float* amax_q, const float* amax_k, const float* amax_v,
+                                                    const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
+                                                    int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
+                                                    int precision, void* workspace, size_t workspace_bytes, void* stream) {
     if (!q || !k || !v || !out || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
@@ -319,6 +322,8 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
     if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
     if (fp8_fmt != QATTN_FMT_E4M3 && fp8_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    if ((amax_q || amax_k || amax_v || ssq_q || ssq_k) && scale_mode != QATTN_SCALE_HEAD) return QATTN_ERR_INVALID_ARG;   // per-head figures
+    if ((ssq_q == nullptr) != (ssq_k == nullptr)) return QATTN_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)) return QATTN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode, is_causal);
@@ -327,7 +332,10 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
     // them instead of sharing the CU, and the chip is power-limited on the attention kernel: the step got 19-31 % SLOWER.)
     unsigned* ws = (unsigned*)workspace;
     void* attn_ws = (unsigned char*)workspace + (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16;
-    const bool moments = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD;
+    // the score-spread estimate needs both heads' sums of squares: from the abs-max pass when it reads q AND k, else from the caller
+    const bool auto_head = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD;
+    const bool ext_moments = auto_head && ssq_q != nullptr;
+    const bool moments = auto_head && !ext_moments && !amax_q && !amax_k;
     // block-scaled V where the hand-scheduled kernel runs (its PV products take the chunk's scale byte) and a head has at most
     // kMomentSplits chunks: V then needs no abs-max pass
 #ifdef QATTN_DEV
@@ -335,13 +343,29 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
 #else
     const bool v_block = fuse_q && (Skv + 63) / 64 <= kMomentSplits;
 #endif
+    const float* ext_amax[3] = {amax_q, amax_k, amax_v};
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
-                              numerics, ws, fuse_q, moments, v_block, st);
+                              numerics, ws, fuse_q, moments, v_block, st, ext_amax);
     if (rc != QATTN_OK) return rc;
     const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
+    const bool q_ext = amax_q != nullptr;
     AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
                fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, attn_ws,
-               v_block ? mom.vexp : nullptr, moments ? mom.part_q : nullptr, moments ? mom.part_k : nullptr, mom.nsplit, fuse_q ? q : nullptr, fuse_q ? mom.amax_q : nullptr, fuse_q ? scale_q : nullptr, numerics};
+               v_block ? mom.vexp : nullptr,
+               moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
+               ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
+               fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
+}
+
+extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
+                                                 void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v, int B,
+                                                 int Hq, int Hkv, int Sq, int Skv, int D, int fp8_fmt, int scale_mode,
+                                                 int numerics, int is_causal, float sm_scale, int precision, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+    return qattn_fp8_quant_attention_forward_ex(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, nullptr, nullptr, nullptr,
+                                                nullptr, nullptr, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal,
+                                                sm_scale, precision, workspace, workspace_bytes, stream);
 }

@@ -81,7 +81,7 @@ struct AttnParams {
     float peak_neff;             // kPeakNeff (0 with peak_r0 = 0)
     const float* ssq_q;          // fused step, head-wise: partial sums of squares of every q head [B*Hq][ssq_stride] and k
     const float* ssq_k;          //   head [B*Hkv][ssq_stride], ssq_n of them valid per head (else nullptr)
-    int ssq_n, ssq_stride;
+    int ssq_n, ssq_stride;       // (a caller-supplied sum of squares per head: one entry, stride 1)
     float peak_z;                // see predicted_r
     float var_mul;               // score variance of head (bh, kvh) ~= sum(ssq_q[bh]) * sum(ssq_k[kvh]) * var_mul
     int total_blocks;            // B * Hq * nqb (set by the launcher); the grid may be smaller: workgroups walk blocks bid, bid + gridDim.x, ...
@@ -98,7 +98,9 @@ struct AttnParams {
     long lse_stride; // floats between the LSE rows of consecutive (b, h)
     float lse_mul;   // 1 (natural log-sum-exp) or -sqrt(D) (QATTN_LSE_REFERENCE)
     const unsigned char* q16;      // fused step: the 16-bit (bf16) Q tensor, quantised row by row in the kernel prologue (else nullptr)
-    const unsigned* q_amax_part;   // fused step: per-block abs-max words of every q head [B*Hq][ssq_stride] (ssq_n valid) from the amax pass
+    const unsigned* q_amax_part;   // fused step: abs-max words (fp32 bits) of every q head, [B*Hq][amax_stride], amax_n valid per head:
+    int amax_n, amax_stride;       //   the abs-max pass's per-block words, or ONE caller-supplied word per head (producer hand-off)
+    int vexp_stride;               // words between the V chunk scale bytes of consecutive kv heads
     float* sq_out;                 // fused step: scale_q [B,Hq] is written by the attention kernel
     int q_numerics;
 #ifdef QATTN_DEV

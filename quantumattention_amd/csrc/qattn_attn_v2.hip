@@ -761,13 +761,13 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // behind the votes for the PV products of every pass of this block; the sweep's first barrier publishes them
     unsigned* vx = vote + 16;
     if (Q16) {
-        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.ssq_stride + i] : 127u;   // (vexp only when nchunks <= kVxWords)
+        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u;   // (vexp only when nchunks <= kVxWords)
     }
     float scale_q16 = 1.0f;
     if (Q16) {
         static_assert(!Q16 || !TOKEN, "the fused Q path is head-wise");
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.ssq_stride, p.ssq_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
     }
     // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210)
@@ -839,9 +839,9 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     float c, scale_q16 = 1.0f;
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.ssq_stride, p.ssq_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         c = p.sm_log2e * scale_q16 * p.sk[kv_head];
-        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.ssq_stride + i] : 127u;
+        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u;
         __syncthreads();
     } else {
         c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];

@@ -237,9 +237,18 @@ __device__ inline unsigned max_partials(const unsigned* part, int n, int lane) {
 // estimate, qattn_attn.h predicted_r).
 constexpr int kMomentSplits = 256;   // >= the abs-max pass's blocks per head
 struct QuantMoments { const float* part_q; const float* part_k; const unsigned* amax_q; const unsigned* vexp; int nsplit; };   // vexp: [B*Hkv][kMomentSplits] E8M0 bytes of the V chunks (block-scaled V)
+#ifndef QATTN_AMAX_INFLIGHT
+#define QATTN_AMAX_INFLIGHT 8
+#endif
+#ifndef QATTN_AMAX_ROUNDS
+#define QATTN_AMAX_ROUNDS 1
+#endif
+constexpr int kAmaxInFlight = QATTN_AMAX_INFLIGHT;   // 16-byte loads a thread of the abs-max pass keeps in flight (tuning knobs:
+constexpr int kAmaxRounds = QATTN_AMAX_ROUNDS;       //   tools/bin variants) and bursts of them per block
 inline int amax_splits(int Sq, int Skv, int D) {
     const long vecs = (long)(Sq > Skv ? Sq : Skv) * D / 8;
-    const long s = (vecs + 2047) / 2048;   // 8 x 16 B per thread and block
+    const long per = 256L * kAmaxInFlight * kAmaxRounds;
+    const long s = (vecs + per - 1) / per;   // kAmaxInFlight x 16 B per thread and burst
     return s < 1 ? 1 : s > kMomentSplits ? kMomentSplits : (int)s;
 }
 inline QuantMoments quant_moments(const unsigned* ws, int B, int Hq, int Hkv, int Sq, int Skv, int D) {
@@ -247,8 +256,12 @@ inline QuantMoments quant_moments(const unsigned* ws, int B, int Hq, int Hkv, in
     const float* s = reinterpret_cast<const float*>(ws + kMomentSplits * (nq + 2 * nk));
     return QuantMoments{s, s + nq * kMomentSplits, ws, ws + kMomentSplits * (nq + nk), amax_splits(Sq, Skv, D)};
 }
+// ext_amax[t] (t = 0, 1, 2 for q, k, v; head-wise only, else nullptr): fp32 abs-max of every head of that tensor as its PRODUCER
+// knows it (the epilogue of the projection / RoPE kernel that wrote it) -- the tensor then takes no part in the abs-max pass, and
+// when none is left the pass is not launched at all (the reference gets this fusion from Inductor, nn.py:410-418).
 int launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                      float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt, int scale_mode,
-                     int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st);
+                     int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st,
+                     const float* const* ext_amax = nullptr);
 
 }  // namespace qattn

@@ -7,47 +7,6 @@
 
 namespace qattn {
 
-// ---------------------------------------------------------------------------------------------------------
-// pass 1 (head-wise only): per-(b,h) abs-max.  |x| of bf16/fp16 is monotone in its low 15 bits, so the reduction
-// runs on packed 16-bit integers; NaN payloads (> inf as integers) propagate like torch's amax.
-// grid = (splits, groups), block = 256.  amax_bits[g] must be zero on entry (hipMemsetAsync in the launcher).
-// ---------------------------------------------------------------------------------------------------------
-template <int IN_FMT>
-__global__ __launch_bounds__(256) void amax_kernel(const uint4* __restrict__ x, unsigned* __restrict__ amax_bits,
-                                                   long vecs_per_group, int splits) {
-    const long g = blockIdx.y;
-    const uint4* xg = x + g * vecs_per_group;
-    const long per = (vecs_per_group + splits - 1) / splits;
-    const long beg = (long)blockIdx.x * per;
-    long end = beg + per;
-    if (end > vecs_per_group) end = vecs_per_group;
-    unsigned m0 = 0, m1 = 0;  // packed 2x u16 running max
-    for (long i = beg + threadIdx.x; i < end; i += 256) {
-        uint4 v = xg[i];
-        unsigned a = v.x & 0x7fff7fffu, b = v.y & 0x7fff7fffu, c = v.z & 0x7fff7fffu, d = v.w & 0x7fff7fffu;
-        // packed u16 max
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        u16x2 pa, pb, pc, pd, p0, p1;
-        __builtin_memcpy(&pa, &a, 4); __builtin_memcpy(&pb, &b, 4); __builtin_memcpy(&pc, &c, 4); __builtin_memcpy(&pd, &d, 4);
-        __builtin_memcpy(&p0, &m0, 4); __builtin_memcpy(&p1, &m1, 4);
-        p0 = __builtin_elementwise_max(p0, __builtin_elementwise_max(pa, pb));
-        p1 = __builtin_elementwise_max(p1, __builtin_elementwise_max(pc, pd));
-        __builtin_memcpy(&m0, &p0, 4); __builtin_memcpy(&m1, &p1, 4);
-    }
-    unsigned m = max(max(m0 & 0xffffu, m0 >> 16), max(m1 & 0xffffu, m1 >> 16));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    __shared__ unsigned red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(red[0], red[1]), max(red[2], red[3]));
-        const float f = load16f<IN_FMT>((unsigned short)m);  // |amax| as fp32 (exact)
-        atomicMax(amax_bits + g, __float_as_uint(f));         // non-negative floats order like their bit patterns
-    }
-}
-
-
 // Transposing copy-out of one staged fp8 tile (64 keys, row-major with VSTRIDE-byte rows in LDS) into its VFRAG chunk.
 // A thread owns 8 keys (the two 4-key groups w = 2wh, 2wh+1 of one (half, hh)) x 4 consecutive d: 8 conflict-free
 // ds_read_b32, two 4x4 byte transposes (8 v_perm_b32 each) and four 8-byte stores -- instead of 32 ds_read_u8 and
@@ -79,83 +38,6 @@ __device__ __forceinline__ void vfrag_copy_out(const unsigned char* img, unsigne
         unsigned char* dst = og_chunk + ((((m * 2 + hh) * 2 + half) * 32 + 4 * dq) << 4) + 8 * wh;
 #pragma unroll
         for (int j = 0; j < 4; j++) *reinterpret_cast<uint2*>(dst + 16 * j) = make_uint2(o[0][j], o[1][j]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// pass 2: quantise one tile of 64 rows x D and emit it in the requested layout.
-// grid = (ceil(S/64), B*H), block = 256.  Each thread owns D/32 vectors of 8 consecutive elements of one row.
-// ---------------------------------------------------------------------------------------------------------
-template <int D, int IN_FMT, int OUT_FMT, int LAYOUT, bool TOKEN>
-__global__ __launch_bounds__(256) void quant_tile_kernel(const uint4* __restrict__ x, uint4* __restrict__ out,
-                                                         float* __restrict__ scale_out,
-                                                         const unsigned* __restrict__ amax_bits, int S, int numerics) {
-    constexpr int VPR = D / 8;            // 16-byte input vectors per row
-    constexpr int ITERS = 64 * VPR / 256; // vectors per thread
-    constexpr int VSTRIDE = D + 4;  // VFRAG staging: fp8 row-major with 4 bytes of row padding (bank spread)
-    __shared__ __attribute__((aligned(16))) unsigned char img[LAYOUT == QATTN_LAYOUT_VFRAG ? 64 * VSTRIDE : 64 * D];
-    const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const int row0 = tile * 64;
-    const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
-    const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-    float scale = 1.0f;
-    if (!TOKEN) {
-        scale = make_scale(__uint_as_float(amax_bits[g]), inv_qmax, numerics, IN_FMT);
-        if (tile == 0 && tid == 0) scale_out[g] = scale;
-    }
-    float rinv = 1.0f / scale;
-    (void)qmax;
-    const uint4* xg = x + (long)g * S * VPR;
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const int vec = it * 256 + tid;
-        const int r = vec / VPR, dv = vec % VPR;
-        const int row = row0 + r;
-        uint4 raw = make_uint4(0, 0, 0, 0);
-        if (row < S) raw = xg[(long)row * VPR + dv];
-        unsigned short e[8];
-        __builtin_memcpy(e, &raw, 16);
-        float f[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) f[j] = load16f<IN_FMT>(e[j]);
-        if (TOKEN) {
-            float a = 0.0f;
-            bool nan = false;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { a = fmaxf(a, fabsf(f[j])); nan |= (f[j] != f[j]); }
-            unsigned ab = nan ? 0x7fc00000u : __float_as_uint(a);
-#pragma unroll
-            for (int off = VPR / 2; off > 0; off >>= 1) ab = max(ab, (unsigned)__shfl_xor((int)ab, off));
-            scale = make_scale(__uint_as_float(ab), inv_qmax, numerics, IN_FMT);
-            if (dv == 0 && row < S) scale_out[(long)g * S + row] = scale;
-        }
-        if (TOKEN) rinv = 1.0f / scale;
-        const int2 lohi = quant8<IN_FMT, OUT_FMT>(raw, scale, rinv);
-        const int lo = lohi.x, hi = lohi.y;
-        const int d0 = dv * 8;
-        if (LAYOUT == QATTN_LAYOUT_ROWMAJOR) {
-            *reinterpret_cast<int2*>(img + r * D + d0) = make_int2(lo, hi);
-        } else if (LAYOUT == QATTN_LAYOUT_KFRAG) {
-            *reinterpret_cast<int2*>(img + kfrag_offset<D>(r, d0)) = make_int2(lo, hi);
-        } else {
-            *reinterpret_cast<int*>(img + r * VSTRIDE + d0) = lo;
-            *reinterpret_cast<int*>(img + r * VSTRIDE + d0 + 4) = hi;
-        }
-    }
-    __syncthreads();
-    // linear write-out of the 64*D-byte image
-    constexpr int OUT_VECS = 64 * D / 16;
-    if (LAYOUT == QATTN_LAYOUT_ROWMAJOR) {
-        uint4* og = out + (long)g * S * (D / 16) + (long)row0 * (D / 16);
-        const int valid = (S - row0 < 64 ? S - row0 : 64) * (D / 16);
-        for (int i = tid; i < valid; i += 256) og[i] = reinterpret_cast<const uint4*>(img)[i];
-    } else if (LAYOUT == QATTN_LAYOUT_KFRAG) {
-        const long Sp = (long)((S + 63) / 64) * 64;
-        uint4* og = out + ((long)g * Sp + row0) * (D / 16);
-        for (int i = tid; i < OUT_VECS; i += 256) og[i] = reinterpret_cast<const uint4*>(img)[i];
-    } else {
-        const long Sp = (long)((S + 63) / 64) * 64;
-        vfrag_copy_out<D, VSTRIDE>(img, reinterpret_cast<unsigned char*>(out) + ((long)g * Sp + row0) * D, tid);
     }
 }
 
@@ -200,6 +82,7 @@ struct QuantJob {
     uint4* out;           // fp8 payload
     float* scale;         // [G] (head) or [G, S] (token)
     unsigned* amax_part;  // [G][kMomentSplits] workspace (head-wise): fp32 bits of the abs-max of every abs-max-pass block's share
+    const unsigned* amax_ext;  // or: [G] fp32 bits of every head's abs-max, supplied by the caller (then amax_part is not used)
     int G, S, layout, token;
     // head-wise q and k of the fused step (else nullptr): every block of the abs-max pass leaves the sum of squares of its
     // share of the head in part[g][block]; the attention kernel adds a head's partial sums in a fixed order (deterministic, no
@@ -211,11 +94,12 @@ struct QuantJobs {
     QuantJob j[3];
     unsigned* vexp;       // block-scaled V (else nullptr): [G of v][kMomentSplits] E8M0 bytes, one per 64-key chunk
     int nsplit;           // abs-max-pass blocks per head = valid entries of amax_part / part per head
+    int zmap[3];          // abs-max pass: blockIdx.z -> job (the tensors that still need the pass)
 };
 
 template <int IN_FMT>
 __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, int D, int splits, int zbase) {
-    const QuantJob& jb = jobs.j[zbase + blockIdx.z];
+    const QuantJob& jb = jobs.j[jobs.zmap[zbase + blockIdx.z]];
     if (jb.token || (int)blockIdx.y >= jb.G) return;
     const long vecs_per_group = (long)jb.S * D / 8;
     const long g = blockIdx.y;
@@ -247,14 +131,14 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
             }
         }
     };
-    // 8 independent 16-byte loads in flight per thread (a plain strided loop kept ~2 and ran at 4.8 TB/s)
+    // kAmaxInFlight independent 16-byte loads in flight per thread (a plain strided loop kept ~2 and ran at 4.8 TB/s)
     long i = beg + threadIdx.x;
-    for (; i + 7 * 256 < end; i += 8 * 256) {
-        uint4 v[8];
+    for (; i + (kAmaxInFlight - 1) * 256 < end; i += kAmaxInFlight * 256) {
+        uint4 v[kAmaxInFlight];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = xg[i + u * 256];
+        for (int u = 0; u < kAmaxInFlight; u++) v[u] = xg[i + u * 256];
 #pragma unroll
-        for (int u = 0; u < 8; u++) fold(v[u]);
+        for (int u = 0; u < kAmaxInFlight; u++) fold(v[u]);
     }
     for (; i < end; i += 256) fold(xg[i]);
     unsigned m = max(max(m0 & 0xffffu, m0 >> 16), max(m1 & 0xffffu, m1 >> 16));
@@ -278,6 +162,11 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
     }
 }
 
+#ifndef QATTN_QUANT_TPB
+#define QATTN_QUANT_TPB 1
+#endif
+constexpr int kQuantTilesPerBlock = QATTN_QUANT_TPB;   // 64-row tiles per block of the quantise pass (tuning knob, tools/bin variants)
+
 template <int D, int IN_FMT, int OUT_FMT>
 __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, int numerics, int ztop) {
     constexpr int VPR = D / 8;             // 16-byte input vectors per row
@@ -291,108 +180,121 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     const QuantJob& jb = jobs.j[ztop - blockIdx.z];
     const int tid = threadIdx.x;
     const int S = jb.S;
-    const int g = jb.G - 1 - (int)blockIdx.y, tile = (S + 63) / 64 - 1 - (int)blockIdx.x;
-    const int row0 = tile * 64;
-    if (g < 0 || tile < 0) return;
+    // a block takes kQuantTilesPerBlock consecutive tiles (downwards); the next tile's rows are requested before the current one is
+    // converted, so a block has loads in flight all the time instead of one latency-bound burst per 16 KiB
+    const int g = jb.G - 1 - (int)blockIdx.y, tile_first = (S + 63) / 64 - 1 - (int)blockIdx.x * kQuantTilesPerBlock;
+    if (g < 0 || tile_first < 0) return;
     const int layout = jb.layout;
     const bool token = jb.token != 0;
-    const float qmax = OUT_FMT == QATTN_FMT_E4M3 ? 448.0f : 57344.0f;
     const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
     float scale = 1.0f;
     if (!token && !(layout == QATTN_LAYOUT_VFRAG && jobs.vexp != nullptr)) {
-        scale = make_scale(__uint_as_float(max_partials(jb.amax_part + (long)g * kMomentSplits, jobs.nsplit, tid & 63)), inv_qmax, numerics, IN_FMT);
-        if (tile == 0 && tid == 0) jb.scale[g] = scale;
+        const unsigned amax_bits = jb.amax_ext ? jb.amax_ext[g] : max_partials(jb.amax_part + (long)g * kMomentSplits, jobs.nsplit, tid & 63);
+        scale = make_scale(__uint_as_float(amax_bits), inv_qmax, numerics, IN_FMT);
+        if (tile_first - kQuantTilesPerBlock < 0 && tid == 0) jb.scale[g] = scale;   // (the block that holds tile 0)
     }
     float rinv = 1.0f / scale;
-    (void)qmax;
     const uint4* xg = jb.x + (long)g * S * VPR;
     const long Sp = (long)((S + 63) / 64) * 64;
     // block-scaled V (vblock_exponent, qattn_common.h): the tile IS the 64-key chunk; its rows are read once, reduced to the
     // chunk's abs-max through LDS, and quantised with the power-of-two scale that the attention kernel gets as one byte
     const bool vblock = layout == QATTN_LAYOUT_VFRAG && jobs.vexp != nullptr;   // uniform over the launch's z slice
-    uint4 held[ITERS];
-    bool exact_tile = false;   // block-scaled V: the chunk holds an inf or a NaN (scale 2^0 all the same) -> NaN bytes must survive
-    if (vblock) {
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        unsigned m0 = 0;
+    auto load_tile = [&](int tile, uint4 (&dst)[ITERS]) {
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
             const int vec = it * 256 + tid;
-            const int row = row0 + vec / VPR;
-            held[it] = make_uint4(0, 0, 0, 0);
-            if (row < S) held[it] = xg[(long)row * VPR + vec % VPR];
-            const unsigned w[4] = {held[it].x & 0x7fff7fffu, held[it].y & 0x7fff7fffu, held[it].z & 0x7fff7fffu, held[it].w & 0x7fff7fffu};
+            const int row = tile * 64 + vec / VPR;
+            dst[it] = make_uint4(0, 0, 0, 0);
+            if (row < S) dst[it] = xg[(long)row * VPR + vec % VPR];
+        }
+    };
+    uint4 held[ITERS];
+    load_tile(tile_first, held);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                u16x2 a, b;
-                __builtin_memcpy(&a, &w[i], 4); __builtin_memcpy(&b, &m0, 4);
-                b = __builtin_elementwise_max(a, b);
-                __builtin_memcpy(&m0, &b, 4);
+    for (int ti = 0; ti < kQuantTilesPerBlock; ti++) {
+        const int tile = tile_first - ti, row0 = tile * 64;
+        if (tile < 0) break;   // (block-uniform)
+        uint4 ahead[ITERS];
+        const bool more = ti + 1 < kQuantTilesPerBlock && tile > 0;
+        if (more) load_tile(tile - 1, ahead);
+        bool exact_tile = false;   // block-scaled V: the chunk holds an inf or a NaN (scale 2^0 all the same) -> NaN bytes must survive
+        if (vblock) {
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            unsigned m0 = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const unsigned w[4] = {held[it].x & 0x7fff7fffu, held[it].y & 0x7fff7fffu, held[it].z & 0x7fff7fffu, held[it].w & 0x7fff7fffu};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    u16x2 a, b;
+                    __builtin_memcpy(&a, &w[i], 4); __builtin_memcpy(&b, &m0, 4);
+                    b = __builtin_elementwise_max(a, b);
+                    __builtin_memcpy(&m0, &b, 4);
+                }
+            }
+            unsigned m = wave_allmax_u32(max(m0 & 0xffffu, m0 >> 16));
+            unsigned* red = reinterpret_cast<unsigned*>(img);
+            if ((tid & 63) == 0) red[tid >> 6] = m;
+            __syncthreads();
+            m = max(max(red[0], red[1]), max(red[2], red[3]));
+            __syncthreads();   // (img is written below)
+            const unsigned amax_bits = __float_as_uint(load16f<IN_FMT>((unsigned short)m));
+            const int e = vblock_exponent(amax_bits, OUT_FMT);
+            exact_tile = (amax_bits & 0x7f800000u) == 0x7f800000u;   // workgroup-uniform
+            scale = __uint_as_float((unsigned)(e + 127) << 23);
+            rinv = __uint_as_float((unsigned)(127 - e) << 23);
+            if (tid == 0) {
+                jobs.vexp[(long)g * kMomentSplits + tile] = (unsigned)(e + 127);
+                if (tile == 0) jb.scale[g] = 1.0f;
             }
         }
-        unsigned m = max(m0 & 0xffffu, m0 >> 16);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-        unsigned* red = reinterpret_cast<unsigned*>(img);
-        if ((tid & 63) == 0) red[tid >> 6] = m;
-        __syncthreads();
-        m = max(max(red[0], red[1]), max(red[2], red[3]));
-        __syncthreads();   // (img is written below)
-        const unsigned amax_bits = __float_as_uint(load16f<IN_FMT>((unsigned short)m));
-        const int e = vblock_exponent(amax_bits, OUT_FMT);
-        exact_tile = (amax_bits & 0x7f800000u) == 0x7f800000u;   // workgroup-uniform
-        scale = __uint_as_float((unsigned)(e + 127) << 23);
-        rinv = __uint_as_float((unsigned)(127 - e) << 23);
-        if (tid == 0) {
-            jobs.vexp[(long)g * kMomentSplits + tile] = (unsigned)(e + 127);
-            if (tile == 0) jb.scale[g] = 1.0f;
+        for (int it = 0; it < ITERS; it++) {
+            const int vec = it * 256 + tid;
+            const int r = vec / VPR, dv = vec % VPR;
+            const int row = row0 + r;
+            const uint4 raw = held[it];
+            if (token) {
+                unsigned short e[8];
+                __builtin_memcpy(e, &raw, 16);
+                float a = 0.0f;
+                bool nan = false;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const float f = load16f<IN_FMT>(e[j]); a = fmaxf(a, fabsf(f)); nan |= (f != f); }
+                unsigned ab = nan ? 0x7fc00000u : __float_as_uint(a);
+#pragma unroll
+                for (int off = VPR / 2; off > 0; off >>= 1) ab = max(ab, (unsigned)__shfl_xor((int)ab, off));
+                scale = make_scale(__uint_as_float(ab), inv_qmax, numerics, IN_FMT);
+                if (dv == 0 && row < S) jb.scale[(long)g * S + row] = scale;
+                rinv = 1.0f / scale;
+            }
+            const int2 lohi = quant8<IN_FMT, OUT_FMT>(raw, scale, rinv, exact_tile);
+            const int lo = lohi.x, hi = lohi.y;
+            const int d0 = dv * 8;
+            if (layout == QATTN_LAYOUT_ROWMAJOR) {
+                if (row < S) reinterpret_cast<int2*>(jb.out)[((long)g * S + row) * (D / 8) + dv] = make_int2(lo, hi);
+            } else if (layout == QATTN_LAYOUT_KFRAG) {
+                const int o = kfrag_offset<D>(r, d0);
+                *reinterpret_cast<int2*>(img + o + ((o >> 9) << 4)) = make_int2(lo, hi);
+            } else {
+                *reinterpret_cast<int*>(img + r * VSTRIDE + d0) = lo;
+                *reinterpret_cast<int*>(img + r * VSTRIDE + d0 + 4) = hi;
+            }
         }
-    }
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const int vec = it * 256 + tid;
-        const int r = vec / VPR, dv = vec % VPR;
-        const int row = row0 + r;
-        uint4 raw = make_uint4(0, 0, 0, 0);
-        if (vblock) raw = held[it];
-        else if (row < S) raw = xg[(long)row * VPR + dv];
-        unsigned short e[8];
-        __builtin_memcpy(e, &raw, 16);
-        float f[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) f[j] = load16f<IN_FMT>(e[j]);
-        if (token) {
-            float a = 0.0f;
-            bool nan = false;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { a = fmaxf(a, fabsf(f[j])); nan |= (f[j] != f[j]); }
-            unsigned ab = nan ? 0x7fc00000u : __float_as_uint(a);
-#pragma unroll
-            for (int off = VPR / 2; off > 0; off >>= 1) ab = max(ab, (unsigned)__shfl_xor((int)ab, off));
-            scale = make_scale(__uint_as_float(ab), inv_qmax, numerics, IN_FMT);
-            if (dv == 0 && row < S) jb.scale[(long)g * S + row] = scale;
+        if (layout != QATTN_LAYOUT_ROWMAJOR) {
+            __syncthreads();
+            if (layout == QATTN_LAYOUT_KFRAG) {
+                uint4* og = jb.out + ((long)g * Sp + row0) * (D / 16);
+                for (int i = tid; i < 64 * D / 16; i += 256) og[i] = *reinterpret_cast<const uint4*>(img + i * 16 + ((i >> 5) << 4));
+            } else {
+                vfrag_copy_out<D, VSTRIDE>(img, reinterpret_cast<unsigned char*>(jb.out) + ((long)g * Sp + row0) * D, tid);
+            }
+            if (more) __syncthreads();   // the image is free for the next tile
         }
-        if (token) rinv = 1.0f / scale;
-        const int2 lohi = quant8<IN_FMT, OUT_FMT>(raw, scale, rinv, exact_tile);
-        const int lo = lohi.x, hi = lohi.y;
-        const int d0 = dv * 8;
-        if (layout == QATTN_LAYOUT_ROWMAJOR) {
-            if (row < S) reinterpret_cast<int2*>(jb.out)[((long)g * S + row) * (D / 8) + dv] = make_int2(lo, hi);
-        } else if (layout == QATTN_LAYOUT_KFRAG) {
-            const int o = kfrag_offset<D>(r, d0);
-            *reinterpret_cast<int2*>(img + o + ((o >> 9) << 4)) = make_int2(lo, hi);
-        } else {
-            *reinterpret_cast<int*>(img + r * VSTRIDE + d0) = lo;
-            *reinterpret_cast<int*>(img + r * VSTRIDE + d0 + 4) = hi;
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) held[it] = ahead[it];
         }
-    }
-    if (layout == QATTN_LAYOUT_ROWMAJOR) return;
-    __syncthreads();
-    if (layout == QATTN_LAYOUT_KFRAG) {
-        uint4* og = jb.out + ((long)g * Sp + row0) * (D / 16);
-        for (int i = tid; i < 64 * D / 16; i += 256) og[i] = *reinterpret_cast<const uint4*>(img + i * 16 + ((i >> 5) << 4));
-    } else {
-        vfrag_copy_out<D, VSTRIDE>(img, reinterpret_cast<unsigned char*>(jb.out) + ((long)g * Sp + row0) * D, tid);
     }
 }
 
@@ -716,32 +618,6 @@ __global__ __launch_bounds__(kTeamThreads) void quant_team_kernel(const OneReadJ
 // ---------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------
-template <int D, int IN_FMT, int OUT_FMT>
-static int launch_quant_dl(const void* x, void* x8, float* scale, int G, int S, int scale_mode, int numerics,
-                           int layout, const unsigned* amax, hipStream_t st) {
-    dim3 grid((S + 63) / 64, G), block(256);
-    const uint4* xi = (const uint4*)x;
-    uint4* xo = (uint4*)x8;
-#define QL(LAY, TOK) hipLaunchKernelGGL((quant_tile_kernel<D, IN_FMT, OUT_FMT, LAY, TOK>), grid, block, 0, st, xi, xo, scale, amax, S, numerics)
-    const bool tok = scale_mode == QATTN_SCALE_TOKEN;
-    if (layout == QATTN_LAYOUT_ROWMAJOR) { if (tok) QL(QATTN_LAYOUT_ROWMAJOR, true); else QL(QATTN_LAYOUT_ROWMAJOR, false); }
-    else if (layout == QATTN_LAYOUT_KFRAG) { if (tok) QL(QATTN_LAYOUT_KFRAG, true); else QL(QATTN_LAYOUT_KFRAG, false); }
-    else if (layout == QATTN_LAYOUT_VFRAG) { if (tok) QL(QATTN_LAYOUT_VFRAG, true); else QL(QATTN_LAYOUT_VFRAG, false); }
-    else return QATTN_ERR_INVALID_ARG;
-#undef QL
-    return QATTN_OK;
-}
-
-template <int D>
-static int launch_quant_d(const void* x, int in_fmt, void* x8, float* scale, int G, int S, int out_fmt, int scale_mode,
-                          int numerics, int layout, const unsigned* amax, hipStream_t st) {
-    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E4M3) return launch_quant_dl<D, QATTN_FMT_BF16, QATTN_FMT_E4M3>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
-    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E5M2) return launch_quant_dl<D, QATTN_FMT_BF16, QATTN_FMT_E5M2>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
-    if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E4M3) return launch_quant_dl<D, QATTN_FMT_FP16, QATTN_FMT_E4M3>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
-    if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E5M2) return launch_quant_dl<D, QATTN_FMT_FP16, QATTN_FMT_E5M2>(x, x8, scale, G, S, scale_mode, numerics, layout, amax, st);
-    return QATTN_ERR_UNSUPPORTED_FMT;
-}
-
 }  // namespace qattn
 
 using namespace qattn;
@@ -755,9 +631,16 @@ extern "C" size_t qattn_fp8_tensor_bytes(int layout, int B, int H, int S, int D)
 extern "C" size_t qattn_quant_workspace_bytes(int B, int H, int S, int D, int scale_mode) {
     (void)S; (void)D;
     if (B <= 0 || H <= 0) return 0;
-    return scale_mode == QATTN_SCALE_HEAD ? (size_t)B * H * sizeof(unsigned) : 0;
+    // head-wise: kMomentSplits abs-max words per head (one per block of the abs-max pass; nothing to zero beforehand)
+    return scale_mode == QATTN_SCALE_HEAD ? (size_t)B * H * qattn::kMomentSplits * sizeof(unsigned) : 0;
 }
 
+template <int D>
+static int launch_quant_multi(const QuantJobs& jobs, int in_fmt, int out_fmt, int numerics, dim3 grid, int ztop, hipStream_t st);
+
+// One tensor through the kernels of the fused q/k/v pre-pass (amax_multi_kernel: packed-u16 max, 8 loads in flight, one word per
+// block and no atomics; quant_multi_kernel: conflict-free LDS images): the single-tensor entry used to have kernels of its own,
+// an older abs-max (2 loads in flight, memset + atomicMax) that ran at 3.4 TB/s against 5.4.
 extern "C" int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale, int B, int H, int S, int D,
                                int out_fmt, int scale_mode, int numerics, int out_layout, void* workspace,
                                size_t workspace_bytes, void* stream) {
@@ -767,25 +650,27 @@ extern "C" int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale
     if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
     if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
     if (out_fmt != QATTN_FMT_E4M3 && out_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (out_layout != QATTN_LAYOUT_ROWMAJOR && out_layout != QATTN_LAYOUT_KFRAG && out_layout != QATTN_LAYOUT_VFRAG) return QATTN_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int G = B * H;
-    unsigned* amax = nullptr;
-    if (scale_mode == QATTN_SCALE_HEAD && (!workspace || workspace_bytes < (size_t)G * sizeof(unsigned))) return QATTN_ERR_WORKSPACE;
-    if (scale_mode == QATTN_SCALE_HEAD) {
-        amax = (unsigned*)workspace;
-        if (hipMemsetAsync(amax, 0, (size_t)G * sizeof(unsigned), st) != hipSuccess) return QATTN_ERR_LAUNCH;
-        const long vecs = (long)S * D / 8;
-        int splits = (int)((vecs + 2047) / 2048);  // 8 x 16 B per thread and block  // >= 16 vectors per thread per split
-        if (splits < 1) splits = 1;
-        if (splits > 256) splits = 256;
-        dim3 grid(splits, G), block(256);
-        if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_kernel<QATTN_FMT_BF16>), grid, block, 0, st, (const uint4*)x, amax, vecs, splits);
-        else hipLaunchKernelGGL((amax_kernel<QATTN_FMT_FP16>), grid, block, 0, st, (const uint4*)x, amax, vecs, splits);
+    const bool head = scale_mode == QATTN_SCALE_HEAD;
+    if (head && (!workspace || workspace_bytes < qattn_quant_workspace_bytes(B, H, S, D, scale_mode))) return QATTN_ERR_WORKSPACE;
+    QuantJobs jobs;
+    jobs.vexp = nullptr;
+    jobs.nsplit = amax_splits(S, S, D);
+    jobs.j[0] = QuantJob{(const uint4*)x, (uint4*)x8, scale, (unsigned*)workspace, nullptr, G, S, out_layout, head ? 0 : 1, nullptr};
+    jobs.j[1] = jobs.j[2] = jobs.j[0];
+    jobs.zmap[0] = jobs.zmap[1] = jobs.zmap[2] = 0;
+    if (head) {
+        dim3 grid(jobs.nsplit, G, 1), block(256);
+        if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, jobs.nsplit, 0);
+        else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, jobs.nsplit, 0);
     }
+    dim3 grid(((S + 63) / 64 + kQuantTilesPerBlock - 1) / kQuantTilesPerBlock, G, 1);
     int rc;
-    if (D == 64) rc = launch_quant_d<64>(x, in_fmt, x8, scale, G, S, out_fmt, scale_mode, numerics, out_layout, amax, st);
-    else if (D == 128) rc = launch_quant_d<128>(x, in_fmt, x8, scale, G, S, out_fmt, scale_mode, numerics, out_layout, amax, st);
-    else rc = launch_quant_d<256>(x, in_fmt, x8, scale, G, S, out_fmt, scale_mode, numerics, out_layout, amax, st);
+    if (D == 64) rc = launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, grid, 0, st);
+    else if (D == 128) rc = launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, grid, 0, st);
+    else rc = launch_quant_multi<256>(jobs, in_fmt, out_fmt, numerics, grid, 0, st);
     if (rc != QATTN_OK) return rc;
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
@@ -868,8 +753,12 @@ extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, 
 
 int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                             float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt,
-                            int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st) {
+                            int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st,
+                            const float* const* ext_amax) {
     const int tok = scale_mode == QATTN_SCALE_TOKEN;
+    const unsigned* ext[3] = {nullptr, nullptr, nullptr};
+    if (ext_amax)
+        for (int t = 0; t < 3; t++) ext[t] = (tok && t < 2) ? nullptr : reinterpret_cast<const unsigned*>(ext_amax[t]);
     const size_t nq = (size_t)B * Hq, nk = (size_t)B * Hkv;
     float* part = reinterpret_cast<float*>(ws + kMomentSplits * (nq + 2 * nk));   // q heads then k heads
     const bool moments = !tok && want_moments;
@@ -877,11 +766,17 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
     jobs.nsplit = amax_splits(Sq, Skv, D);
     const bool vblock = v_block && !tok && (Skv + 63) / 64 <= kMomentSplits;   // V's 256 words per head hold the chunks' scale bytes instead of abs-max words
     jobs.vexp = vblock ? ws + kMomentSplits * (nq + nk) : nullptr;
-    jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok,
+    jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, ext[0], B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok,
                          moments ? part : nullptr};
-    jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + kMomentSplits * nq, B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
+    jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + kMomentSplits * nq, ext[1], B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
                          moments ? part + nq * kMomentSplits : nullptr};
-    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + kMomentSplits * (nq + nk), B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0, nullptr};
+    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + kMomentSplits * (nq + nk), ext[2], B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0, nullptr};
+    // the tensors the abs-max pass still has to read: head-wise ones without a caller-supplied abs-max (q, k: not with token-wise
+    // scales; V always has one scale per head, or none of its own when block-scaled)
+    int npass = 0;
+    for (int t = 0; t < 3; t++)
+        if (!ext[t] && (t == 2 ? !vblock : !tok)) jobs.zmap[npass++] = t;
+    for (int t = npass; t < 3; t++) jobs.zmap[t] = 0;
     // (Tried and dropped: one tensor at a time -- amax then quantise, hoping the re-read hits the 256 MiB Infinity Cache --
     // was 13 % slower than the two fused launches; a one-pass register-resident variant with a cross-workgroup amax
     // exchange was 2-6x slower, the agent-scope atomics + spinning cost more than the second read.  A third variant --
@@ -898,13 +793,16 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
         // (experiment: the one-read team kernel for head-wise K and V; one workgroup per CU, whole teams per XCD)
         const int NS = (Skv + kSliceBytes / (D * 2) - 1) / (kSliceBytes / (D * 2));
         const int tpx = NS >= 1 ? 32 / NS : 0;
-        const bool oneread = !tok && tpx >= 1 && D <= 128 && !vblock && one_read_enabled();   // (the team kernel scales V per head)
+        const bool oneread = !tok && tpx >= 1 && D <= 128 && !vblock && !ext_amax && one_read_enabled();   // (the team kernel scales V per head)
 #else
         const bool oneread = false;
 #endif
-        dim3 grid(splits, oneread ? B * Hq : Gmax, oneread ? 1 : vblock ? 2 : 3), block(256);   // (block-scaled V: no abs-max pass over v)
-        if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, splits, 0);
-        else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, splits, 0);
+        dim3 grid(splits, oneread ? B * Hq : Gmax, oneread ? 1 : npass), block(256);   // (block-scaled V, supplied abs-max: not in the pass)
+        if (oneread) { jobs.zmap[0] = 0; }
+        if (oneread || npass > 0) {
+            if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, splits, 0);
+            else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, splits, 0);
+        }
 #ifdef QATTN_DEV
         if (oneread) {
             static unsigned long long* granules = nullptr;   // dev only: 2 * G * NS granules, one allocation for the process
@@ -927,7 +825,7 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
             const bool ok = D == 64 ? launch_quant_oneread<64>(jb, in_fmt, out_fmt, numerics, st) : launch_quant_oneread<128>(jb, in_fmt, out_fmt, numerics, st);
             if (!ok) return QATTN_ERR_LAUNCH;
             if (skip_q_payload) return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
-            dim3 gq((Sq + 63) / 64, B * Hq, 1);   // Q payload: the two-pass quantise over job 0 only
+            dim3 gq(((Sq + 63) / 64 + kQuantTilesPerBlock - 1) / kQuantTilesPerBlock, B * Hq, 1);   // Q payload: the two-pass quantise over job 0 only
             const int rq = D == 64 ? launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, gq, 0, st) : launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, gq, 0, st);
             if (rq != QATTN_OK) return rq;
             return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
@@ -935,7 +833,7 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
 #endif
     }
     // the quantise pass walks jobs ztop, ztop-1, ...: with skip_q_payload only v and k (blockIdx.z = 0, 1)
-    dim3 grid(((skip_q_payload ? Skv : Smax) + 63) / 64, skip_q_payload ? B * Hkv : Gmax, skip_q_payload ? 2 : 3);
+    dim3 grid((((skip_q_payload ? Skv : Smax) + 63) / 64 + kQuantTilesPerBlock - 1) / kQuantTilesPerBlock, skip_q_payload ? B * Hkv : Gmax, skip_q_payload ? 2 : 3);
     int rc;
     if (D == 64) rc = launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, grid, 2, st);
     else if (D == 128) rc = launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, grid, 2, st);

@@ -36,7 +36,7 @@ def test_abi_size_queries_and_error_codes_need_no_gpu():
     assert L.qattn_fp8_tensor_bytes(_native.LAYOUT_ROWMAJOR, 4, 32, 4096, 128) == 4 * 32 * 4096 * 128
     assert L.qattn_fp8_tensor_bytes(_native.LAYOUT_KFRAG, 1, 2, 200, 128) == 1 * 2 * 256 * 128  # padded to 64 keys
     assert L.qattn_fp8_tensor_bytes(_native.LAYOUT_VFRAG, 1, 2, 64, 64) == 2 * 64 * 64
-    assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_HEAD) == 4 * 32 * 4
+    assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_HEAD) == 4 * 32 * 256 * 4   # 256 per-block abs-max words per head
     assert L.qattn_quant_workspace_bytes(4, 32, 4096, 128, _native.SCALE_TOKEN) == 0
     assert L.qattn_quant_qkv_workspace_bytes(4, 32, 8) == 4 * 256 * ((128 + 64) + 160)   # per-block abs-max words of q, k, v | per-block sums of squares of q and k
     attn_ws = 32 + 4 * 32 * 128 * 4      # block hand-out counters of a causal launch | one word per 32-row query group
@@ -70,7 +70,10 @@ def test_public_names_and_signatures_mirror_the_reference():
     ]
     sdpa = ["query", "key", "value", "attn_mask", "dropout_p", "is_causal", "scale"]
     assert list(inspect.signature(qa.attn_func).parameters) == sdpa                                   # interface.py:41-50
-    assert list(inspect.signature(qa.fp8_attn_func).parameters) == sdpa + ["scale_q", "scale_k", "scaling_method"]  # :101-113
+    # :101-113, followed by this build's keyword-only extension (the producer-side abs-max hand-off)
+    assert list(inspect.signature(qa.fp8_attn_func).parameters) == sdpa + ["scale_q", "scale_k", "scaling_method", "amax_q", "amax_k"]
+    assert all(inspect.signature(qa.fp8_attn_func).parameters[n].kind is inspect.Parameter.KEYWORD_ONLY and
+               inspect.signature(qa.fp8_attn_func).parameters[n].default is None for n in ("amax_q", "amax_k"))
     assert list(inspect.signature(qa.fp8_token_wise_attn_func).parameters) == sdpa + ["scale_q", "scale_k"]         # :179-190
     assert list(inspect.signature(qa.nn.can_use_attention).parameters)[:8] == sdpa + ["scaling_method"]  # nn.py:282-292
     for flag in ("skip_supported_check", "force_eager_fallback"):                                   # config.py:27-28

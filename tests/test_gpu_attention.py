@@ -348,13 +348,52 @@ def test_c_abi_error_codes_instead_of_exceptions():
     x = torch.zeros(1, 2, 64, 128, dtype=torch.bfloat16, device="cuda")
     x8 = torch.zeros(1, 2, 64, 128, dtype=torch.uint8, device="cuda")
     s = torch.zeros(1, 2, dtype=torch.float32, device="cuda")
-    ws = torch.zeros(4, dtype=torch.uint8, device="cuda")
-    quant = lambda D=128, in_fmt=2, out_fmt=0, ws_bytes=8: L.qattn_quant_fp8(P(x), in_fmt, P(x8), P(s), 1, 2, 64, D, out_fmt, 0, 0, 0,
-                                                                              P(ws), ctypes.c_size_t(ws_bytes), None)
-    assert quant(ws_bytes=4) == -4                                      # workspace too small (needs 2 heads x 4 bytes)
+    qneed = L.qattn_quant_workspace_bytes(1, 2, 64, 128, 0)
+    ws = torch.zeros(qneed, dtype=torch.uint8, device="cuda")
+    quant = lambda D=128, in_fmt=2, out_fmt=0, ws_bytes=qneed: L.qattn_quant_fp8(P(x), in_fmt, P(x8), P(s), 1, 2, 64, D, out_fmt, 0, 0, 0,
+                                                                                 P(ws), ctypes.c_size_t(ws_bytes), None)
+    assert quant() == 0 and quant(ws_bytes=qneed - 4) == -4             # workspace too small (256 abs-max words per head)
     assert quant(D=100) == -2 and quant(in_fmt=0) == -3 and quant(out_fmt=2) == -3
     assert L.qattn_pack16(P(x), P(x8), 1, 2, 64, 96, 3, None) == -2     # head_dim not in {64,128,256}
     assert L.qattn_attention_forward_16(P(x), P(x), P(x), P(out), None, 1, 2, 2, 64, 64, 128, 0, 0, f0, 0, None) == -3
     torch.cuda.synchronize()
     for code in (0, -1, -2, -3, -4, -5, -6):
         assert len(L.qattn_strerror(code)) > 0
+
+
+@pytest.mark.parametrize("D,causal,fp8,dtype", [(128, False, "e4m3", torch.bfloat16), (128, True, "e5m2", torch.bfloat16),
+                                               (128, False, "e4m3", torch.float16), (64, True, "e4m3", torch.bfloat16),
+                                               (256, False, "e4m3", torch.bfloat16)])
+def test_producer_supplied_abs_max_is_bit_identical(D, causal, fp8, dtype):
+    """SURVEY section 8f-4 / VERDICT r2 item 4a: the reference's quantiser is traced into the caller's graph and fused with
+    whatever produced q and k (nn.py:410-418).  Counterpart here: qattn_fp8_quant_attention_forward_ex takes the per-head
+    abs-max (and, optionally, sums of squares) a producer already has; the abs-max launch then skips those tensors.  With the
+    exact abs-max the step's output is bit-identical to the two-pass result, whatever subset is supplied."""
+    torch.manual_seed(21)
+    B, Hq, Hkv, S = 2, 4, 2, 1000
+    q = torch.randn(B, Hq, S, D, dtype=dtype, device="cuda")
+    k = torch.randn(B, Hkv, S, D, dtype=dtype, device="cuda") * 1.7
+    v = torch.randn(B, Hkv, S, D, dtype=dtype, device="cuda") * 0.3
+    kw = dict(is_causal=causal, fp8_dtype=TDT[fp8])
+    base = _native.fp8_quant_attention_forward(q, k, v, **kw)
+    amax = lambda t: t.abs().amax(dim=(2, 3)).float()
+    ssq = lambda t: (t.float() ** 2).sum(dim=(2, 3))
+    aq, ak, av = amax(q), amax(k), amax(v)
+    for extra in (dict(amax_q=aq, amax_k=ak), dict(amax_q=aq), dict(amax_k=ak, amax_v=av), dict(amax_q=aq, amax_k=ak, amax_v=av),
+                  dict(amax_q=aq, amax_k=ak, amax_v=av, ssq_q=ssq(q), ssq_k=ssq(k))):
+        got = _native.fp8_quant_attention_forward(q, k, v, **kw, **extra)
+        assert torch.equal(got, base), sorted(extra)
+    if fp8 == "e4m3":   # ... and through the reference-shaped interface (keyword-only extension of fp8_attn_func)
+        assert torch.equal(qa.fp8_attn_func(q, k, v, is_causal=causal, amax_q=aq, amax_k=ak), qa.fp8_attn_func(q, k, v, is_causal=causal))
+    # an upper bound instead of the exact abs-max is safe (a coarser scale, no clipping): other bits, the same attention
+    loose = _native.fp8_quant_attention_forward(q, k, v, **kw, amax_q=aq * 1.5, amax_k=ak * 1.5)
+    assert not torch.equal(loose, base) and torch.isfinite(loose).all()
+    assert (loose.float() - base.float()).pow(2).mean().sqrt().item() < (2e-2 if fp8 == "e5m2" else 1e-2)
+    with pytest.raises(ValueError):
+        _native.fp8_quant_attention_forward(q, k, v, **kw, amax_q=aq[:, :1])                      # wrong shape
+    with pytest.raises(ValueError):
+        _native.fp8_quant_attention_forward(q, k, v, **kw, scaling="token-wise", amax_q=aq)        # per-head figures need head-wise scales
+    with pytest.raises(ValueError):
+        _native.fp8_quant_attention_forward(q, k, v, **kw, ssq_q=ssq(q))                           # both or neither
+    with pytest.raises(ValueError):
+        qa.nn.fp8_attention(q, k, v, is_causal=causal, scaling_method="token-wise", amax_q=aq)
