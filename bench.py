@@ -23,7 +23,8 @@ The JSON line also carries
                   minus attention), each against 603.98 MB of algorithmic bytes at C2;
   sustained_ms_per_step, c3_*, c5_* -- a >= 2 s back-to-back run and the causal / long-context configs (N=1 only);
   under_load / attn_under_load / joules_per_step -- socket power, cap and shader clock (rocm-smi) while the step, resp. the
-                  attention launch alone, keeps the queue full;
+                  attention launch alone, keeps the queue full;  in_kernel_clock_ghz -- s_memtime / s_memrealtime of every wave's KV sweep
+                  (median), from the stamped measurement instantiation of the attention kernel after 600 back-to-back steps;
   reference_bench_shape -- the reference's own benchmark grid B16 H16 S8192, D in {64,128,256}, causal and not
                   (tests/test_interface.py:95-102,141-156), through the same fp8_attn_func step;
   accuracy     -- max-abs / rmse of the step's output on a head slice of C2, C3 and C5 against fp64 SDPA (torch, on the GPU) of the
@@ -419,6 +420,15 @@ def run_rank(args):
                     if line["attn_under_load"]:
                         line["attn_under_load"]["ms_per_launch"] = e0.elapsed_time(e1) / n_calls
                 del q8, kf, vf
+                # the clock the chip holds INSIDE the attention kernel while the step loops: shader cycles / 100 MHz ticks of every wave's
+                # KV sweep, from the stamped instantiation of the same kernel (qattn_fp8_quant_attention_forward_stamped)
+                if D == 128 and args.fp8 == "e4m3":
+                    try:
+                        ghz, cyc, _ = _native.measure_attention_clock(q, k, v, is_causal=args.causal, precision=args.precision, calls=600)
+                        line["in_kernel_clock_ghz"] = ghz
+                        line["in_kernel_sweep_cycles_per_wave"] = cyc
+                    except Exception as exc:
+                        print(f"[bench] in-kernel clock skipped: {exc}", file=sys.stderr)
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
             def extra(Bx, Hx, Sx, causal, fp8, n):
                 qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))

@@ -213,6 +213,21 @@ int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k, const voi
                                          void* stream);
 
 /*
+ * Measurement aid (bench.py `in_kernel_clock_ghz`): the same step as qattn_fp8_quant_attention_forward, run on an instantiation of the
+ * attention kernel in which every wave brackets its KV sweep with the shader-cycle counter (s_memtime) and the 100 MHz real-time
+ * counter (s_memrealtime).  `stamps` receives {cycles, ticks} per wave, 8 waves per 256-row query block, blocks in (b, h, block)
+ * order: qattn_attention_stamp_bytes() bytes.  cycles / ticks x 0.1 is the clock in GHz the chip held inside the kernel.  Only where
+ * the hand-scheduled kernel runs the fused step (D = 128, bf16, head-wise, e4m3), else QATTN_ERR_UNSUPPORTED_FMT; outputs are those
+ * of the unstamped step.  The product entries execute no stamp.
+ */
+size_t qattn_attention_stamp_bytes(int B, int Hq, int Sq);
+int qattn_fp8_quant_attention_forward_stamped(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8, void* k8,
+                                              void* v8, float* scale_q, float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq,
+                                              int Skv, int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
+                                              int precision, void* workspace, size_t workspace_bytes, void* stamps, size_t stamps_bytes,
+                                              void* stream);
+
+/*
  * 16-bit sibling path: the non-fp8 build of the same kernel (TK_ATTN_IS_FP8 undefined, tk/attention.py:212,238-240,
  * 289-313) behind `quantum_attn::attention_forward(query, key, value, scale=None, is_causal=False)`
  * (src/quantum_attn/ops.py:17-45).  q/out row-major [B,Hq,Sq,D] bf16 or fp16 (`fmt`); k16/v16 are the key/value

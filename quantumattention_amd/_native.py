@@ -32,6 +32,7 @@ EXPORTS = (
     "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16", "qattn_fp8_quant_attention_forward",
     "qattn_attention_workspace_bytes", "qattn_lse_row_stride", "qattn_fp8_quant_attention_workspace_bytes",
     "qattn_profile_attention", "qattn_last_attention_ms", "qattn_vblock_exponent", "qattn_fp8_quant_attention_forward_ex",
+    "qattn_attention_stamp_bytes", "qattn_fp8_quant_attention_forward_stamped",
 )
 
 _lib = None
@@ -89,6 +90,10 @@ def lib() -> ctypes.CDLL:
     L.qattn_fp8_quant_attention_forward_ex.restype = i
     L.qattn_fp8_quant_attention_forward_ex.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                                        i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp]
+    L.qattn_attention_stamp_bytes.restype = sz
+    L.qattn_attention_stamp_bytes.argtypes = [i, i, i]
+    L.qattn_fp8_quant_attention_forward_stamped.restype = i
+    L.qattn_fp8_quant_attention_forward_stamped.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp, sz, vp]
     if L.qattn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libqattn_hip.so ABI {L.qattn_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = L
@@ -331,3 +336,36 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
             NUMERICS[numerics], int(is_causal), float(sm_scale), _precision(precision), ws.data_ptr(), ws_bytes, _stream(q))
     _check(rc, "qattn_fp8_quant_attention_forward_ex")
     return out
+
+
+def measure_attention_clock(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, is_causal: bool = False, precision: str = "auto",
+                            fp8_dtype=torch.float8_e4m3fn, calls: int = 50):
+    """Measurement aid: run the fused step `calls` times back to back on the stamped instantiation of the attention kernel
+    (qattn_fp8_quant_attention_forward_stamped) and return (median in-kernel clock in GHz over the waves of the LAST call, median
+    sweep cycles per wave, output of the last call).  D = 128, bf16, head-wise, e4m3 only."""
+    B, Hq, Hkv, Sq, Skv, D = _check_qkv(q, k, v)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    L = lib()
+    dev = q.device
+    with torch.cuda.device(dev):
+        out = torch.empty_like(q)
+        q8 = torch.empty((B, Hq, Sq, D), dtype=torch.uint8, device=dev)
+        kf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
+        vf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
+        sq = torch.empty((B, Hq), dtype=torch.float32, device=dev)
+        sk, sv = (torch.empty((B, Hkv), dtype=torch.float32, device=dev) for _ in range(2))
+        ws_bytes = L.qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        st_bytes = L.qattn_attention_stamp_bytes(B, Hq, Sq)
+        stamps = torch.zeros((st_bytes // 8,), dtype=torch.int64, device=dev)
+        for _ in range(calls):
+            rc = L.qattn_fp8_quant_attention_forward_stamped(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(), vf.data_ptr(),
+                sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), SCALE_HEAD, NUMERICS["compiled"],
+                int(is_causal), 0.0, _precision(precision), ws.data_ptr(), ws_bytes, stamps.data_ptr(), st_bytes, _stream(q))
+            _check(rc, "qattn_fp8_quant_attention_forward_stamped")
+        torch.cuda.synchronize(dev)
+    s = stamps.view(-1, 2).double().cpu()
+    s = s[s[:, 1] > 0]
+    clock = (s[:, 0] / s[:, 1] * 0.1)
+    return float(clock.median()), float(s[:, 0].median()), out

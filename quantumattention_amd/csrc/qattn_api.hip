@@ -80,6 +80,7 @@ struct AttnCall {
     float* sq_out;
     int q_numerics;
     int amax_n, amax_stride;
+    unsigned long long* stamps;   // measurement entry (else nullptr)
 };
 
 // attention workspace = [SchedState of the hand-scheduled kernel's causal launches | one flag word per (b, h, 32-row group)]
@@ -133,6 +134,8 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.lse_stride = (long)qattn_lse_row_stride(a.Sq, a.lse_layout);
     p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
     p.q16 = (const unsigned char*)a.q16; p.q_amax_part = a.q_amax_part; p.sq_out = a.sq_out; p.q_numerics = a.q_numerics;
+    p.stamp_buf = a.stamps;
+    if (a.stamps && !(a.q16 && attn_v2_covers(a.D, a.is_causal, a.scale_mode) && a.qk_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
     bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
 #ifdef QATTN_DEV
     const DevEnv& e = dev_env();
@@ -297,7 +300,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
     if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
     AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
-               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0};
+               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
     return attention_impl(a, (hipStream_t)stream, ds);
 }
@@ -308,12 +311,12 @@ extern "C" size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int H
     return (qattn_quant_qkv_workspace_bytes(B, Hq, Hkv) + 15) / 16 * 16 + qattn_attention_workspace_bytes(B, Hq, Sq);
 }
 
-extern "C" int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
-                                                    void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v,
-                                                    const float* amax_q, const float* amax_k, const float* amax_v,
-                                                    const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
-                                                    int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
-                                                    int precision, void* workspace, size_t workspace_bytes, void* stream) {
+static int quant_attention_impl(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
+                                void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v,
+                                const float* amax_q, const float* amax_k, const float* amax_v,
+                                const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
+                                int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
+                                int precision, void* workspace, size_t workspace_bytes, void* stream, unsigned long long* stamps) {
     if (!q || !k || !v || !out || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
@@ -355,9 +358,35 @@ extern "C" int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, stamps};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
+}
+
+extern "C" int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
+                                                    void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v,
+                                                    const float* amax_q, const float* amax_k, const float* amax_v,
+                                                    const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
+                                                    int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
+                                                    int precision, void* workspace, size_t workspace_bytes, void* stream) {
+    return quant_attention_impl(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, amax_q, amax_k, amax_v, ssq_q, ssq_k, B, Hq, Hkv,
+                                Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" size_t qattn_attention_stamp_bytes(int B, int Hq, int Sq) {
+    if (B <= 0 || Hq <= 0 || Sq <= 0) return 0;
+    return 2 * sizeof(unsigned long long) * (size_t)B * Hq * ceil_div(Sq, kQPerWG) * kWaves;
+}
+
+extern "C" int qattn_fp8_quant_attention_forward_stamped(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
+                                                         void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v, int B,
+                                                         int Hq, int Hkv, int Sq, int Skv, int D, int fp8_fmt, int scale_mode,
+                                                         int numerics, int is_causal, float sm_scale, int precision, void* workspace,
+                                                         size_t workspace_bytes, void* stamps, size_t stamps_bytes, void* stream) {
+    if (!stamps || stamps_bytes < qattn_attention_stamp_bytes(B, Hq, Sq)) return QATTN_ERR_WORKSPACE;
+    return quant_attention_impl(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, nullptr, nullptr, nullptr, nullptr, nullptr, B, Hq,
+                                Hkv, Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, workspace, workspace_bytes, stream,
+                                (unsigned long long*)stamps);
 }
 
 extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,

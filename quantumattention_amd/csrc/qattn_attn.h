@@ -103,6 +103,7 @@ struct AttnParams {
     int vexp_stride;               // words between the V chunk scale bytes of consecutive kv heads
     float* sq_out;                 // fused step: scale_q [B,Hq] is written by the attention kernel
     int q_numerics;
+    unsigned long long* stamp_buf;   // measurement entry only (else nullptr): {shader cycles, 100 MHz ticks} of every wave's KV sweep
 #ifdef QATTN_DEV
     int waves;       // waves per workgroup of the v2 kernel (8 or 4): nqb is computed for waves*32 rows
     int lds_pad;     // force this dynamic-LDS size (occupancy experiments), 0 = natural
@@ -201,6 +202,24 @@ __device__ inline unsigned pack2_f16(float a, float b) {
     unsigned u;
     __builtin_memcpy(&u, &h, 4);
     return u;
+}
+
+// v_max3_f32 through asm: on MFMA results the compiler otherwise adds a canonicalising v_max_f32 x, x, x per chain.  Interleave
+// THREE independent chains: hipcc pads wait states between an asm statement and a VALU that reads its output unless two other
+// instructions sit in between.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// the maximum of the 32 scores a lane holds of one 64-key chunk (two 32-key tiles)
+__device__ __forceinline__ float max32_raw(const v16f& s0, const v16f& s1) {
+    float a = max3_raw(s0[0], s0[1], s0[2]), b = max3_raw(s0[3], s0[4], s0[5]), c = max3_raw(s0[6], s0[7], s0[8]);
+    a = max3_raw(a, s0[9], s0[10]); b = max3_raw(b, s0[11], s0[12]); c = max3_raw(c, s0[13], s0[14]);
+    a = max3_raw(a, s0[15], s1[0]); b = max3_raw(b, s1[1], s1[2]); c = max3_raw(c, s1[3], s1[4]);
+    a = max3_raw(a, s1[5], s1[6]); b = max3_raw(b, s1[7], s1[8]); c = max3_raw(c, s1[9], s1[10]);
+    a = max3_raw(a, s1[11], s1[12]); b = max3_raw(b, s1[13], s1[14]); c = max3_raw(c, s1[15], s1[15]);
+    return max3_raw(a, b, c);
 }
 
 __device__ inline v8i lds_read_frag(const unsigned char* base) {

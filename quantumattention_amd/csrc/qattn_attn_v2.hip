@@ -189,11 +189,6 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
     pv[w] = (int)b;
 }
 
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 
 #define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #ifndef QATTN_DEV
@@ -503,7 +498,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
-    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && (ABL & ~512) == 0;   // (run-time: only passes that check their rows ask for it)
+    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && (ABL & ~(512 | 1024)) == 0;   // (run-time: only passes that check their rows ask for it)
 #ifdef QATTN_DEV
     if (p.no_forecast) forecast = false;   // QATTN_NO_FORECAST=1: A/B switch
 #endif
@@ -623,6 +618,16 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
+    // ABL & 1024: the MEASUREMENT instantiation (qattn_fp8_quant_attention_forward_stamped): every wave brackets its KV sweep with
+    // the shader-cycle counter and the 100 MHz real-time counter; their ratio is the clock the chip held INSIDE the kernel
+    // (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to a buffer of their own, nothing is computed from them; the
+    // product instantiations (ABL = 0) execute no stamp.
+    unsigned long long stamp_t0 = 0, stamp_r0 = 0;
+    if constexpr ((ABL & 1024) != 0) {
+        stamp_t0 = __builtin_amdgcn_s_memtime();
+        stamp_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) alone: the sweep's own LDS waits stay counted
+    }
     // the Q^T rows travel to LDS while the first K/V stages do; QREG kernels then keep the fragments in registers
     auto load_q_frags = [&]() {
         load_q();
@@ -634,6 +639,14 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
                                                                                 !TWO && check_peaked, vote, vx))
         return kPassRedo;   // forecast: the block is peaked, nothing was stored
+    if constexpr ((ABL & 1024) != 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && p.stamp_buf) {
+            const long wid = (bh * p.nqb + (q0 - wave * kQPerWave) / (NW * kQPerWave)) * NW + wave;
+            p.stamp_buf[2 * wid] = t1 - stamp_t0;
+            p.stamp_buf[2 * wid + 1] = r1 - stamp_r0;
+        }
+    }
 #ifdef QATTN_DEV
     if (p.dbg & 16) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -1043,6 +1056,15 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
         return QATTN_OK;
     }
 #endif
+    if constexpr (FMT == QATTN_FMT_E4M3 && Q16 && BYTE && NW == 8 && !TOKEN) {
+        if (p.stamp_buf) {   // measurement entry: the same kernel with the two clock stamps per wave
+            auto kern1 = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 1024, Q16, CHECK>;
+            if (hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
+            hipLaunchKernelGGL(kern1, dim3(grid), dim3(NW * 64), lds, st, p);
+            return QATTN_OK;
+        }
+    }
+    if (p.stamp_buf) return QATTN_ERR_UNSUPPORTED_FMT;   // (only the fused e4m3 step has a stamped instantiation)
     auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 0, Q16, CHECK>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);

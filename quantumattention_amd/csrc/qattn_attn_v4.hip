@@ -147,6 +147,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
         for (int w = 0; w < 8; w++) ones[w] = one;
     }
     float m_run = -1.0e30f, m_true = -1.0e30f, l_run = 0.0f;
+    float lim = -1.0e30f, off8 = 0.0f;   // m_run + thr / c and the byte formula's additive constant (set by the first chunk's fix-up)
     constexpr float U16 = 1.0f / 65535.0f;
     const float c8 = (8.0f * U16) * c;
     const int frag_lane_off = (hh << 10) + (ql << 4);
@@ -227,18 +228,13 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
             if (lane == 0) vote[wave] = mine ? 1u : 0u;
         }
         // ---- running max; rescale only when a row's max grew past the headroom of the shifted exponent
-        float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
-        mx = fmaxf(mx, s0[15]);
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
+        float mx = max32_raw(s0, s1);
         {
             auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            m_true = max3_raw(m_true, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            mx = max3_raw(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
         }
-        m_true = fmaxf(m_true, mx);
-        if (__builtin_expect(__any((mx - m_run) * c > kRescaleThrByte) != 0, 0)) {
+        if (__builtin_expect(__any(mx > lim) != 0, 0)) {   // (mx - m_run) c > thr: P' could overflow e4m3
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
 #pragma unroll
@@ -256,11 +252,13 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
                 l2_run *= alpha * alpha;
             }
             m_run = m_new;
+            // the two values that change only here, kept instead of re-derived every chunk
+            lim = m_new + kRescaleThrByte / c;
+            off8 = __builtin_fmaf((-8.0f * U16) * m_new, c, (8.0f * kPShiftByte + 56.0f + kByteBias) * U16);
         }
         v8i pv, pl;
         if (BYTE) {
             // ---- P = e4m3 bytes of 2^(c*(s - m) + shift)
-            const float off8 = __builtin_fmaf((-8.0f * U16) * m_run, c, (8.0f * kPShiftByte + 56.0f + kByteBias) * U16);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 pv[j] = byte_exp4(s0[4 * j], s0[4 * j + 1], s0[4 * j + 2], s0[4 * j + 3], c8, off8);

@@ -397,3 +397,16 @@ def test_producer_supplied_abs_max_is_bit_identical(D, causal, fp8, dtype):
         _native.fp8_quant_attention_forward(q, k, v, **kw, ssq_q=ssq(q))                           # both or neither
     with pytest.raises(ValueError):
         qa.nn.fp8_attention(q, k, v, is_causal=causal, scaling_method="token-wise", amax_q=aq)
+
+
+def test_stamped_measurement_entry_reports_a_clock_and_the_same_output():
+    """qattn_fp8_quant_attention_forward_stamped (bench.py in_kernel_clock_ghz): the stamped instantiation computes what the product
+    kernel computes, and cycles / 100 MHz ticks of the waves' sweeps is a plausible shader clock."""
+    torch.manual_seed(8)
+    q, k, v = (torch.randn(2, 8, 2048, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    for causal in (False, True):
+        ghz, cycles, out = _native.measure_attention_clock(q, k, v, is_causal=causal, calls=20)
+        assert torch.equal(out, qa.fp8_attn_func(q, k, v, is_causal=causal))
+        assert 0.3 < ghz < 2.6 and cycles > 1000, (ghz, cycles)
+    with pytest.raises(RuntimeError):   # D = 64 runs on the templated kernel: no stamped instantiation
+        _native.measure_attention_clock(q[..., :64].contiguous(), k[..., :64].contiguous(), v[..., :64].contiguous())

@@ -43,7 +43,9 @@ with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
 
 attn = [k for k in summary if "attn_fwd_kernel" in k]
 # the in-step instantiation (last template argument Q16 = true: it reads Q as bf16) when present, else the plain one
-fused = [k for k in attn if k.rstrip().rstrip(">").rstrip().endswith("true")]
+def _targs(k):   # template arguments of attn_fwd_kernel_v2<D, NW, QK, V, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>
+    return [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k and ">" in k else []
+fused = [k for k in attn if "kernel_v2" in k and len(_targs(k)) >= 9 and _targs(k)[8] == "true"]
 if attn:
     key = fused[0] if fused else attn[0]
     s = summary[key]
@@ -64,7 +66,7 @@ if attn:
         out["kv_restream_bytes_without_l2_reuse"] = B * H * (S // 256) * (S * D * 2) // 2
     with open(os.path.join(dst, "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
-    if shape == (4, 32, 4096, 128) and not causal:
+    if shape == (4, 32, 4096, 128) and not causal and fused:   # the bench line's kernel only (not the token-wise / 16-bit profiles)
         with open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json"), "w") as f:
             json.dump(out, f, indent=1)
     print(json.dumps(out))
