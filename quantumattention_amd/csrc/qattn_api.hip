@@ -114,6 +114,12 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.causal_group = 1;
     for (int g = kCausalHeadGroup; g > 1; g >>= 1)
         if (p.xcd_remap && ((a.B * a.Hq) >> 3) % g == 0 && (size_t)g * 2 * a.Skv * a.D <= kCausalGroupBytes) { p.causal_group = g; break; }
+    // causal AUTO: the blocks right above the two-term line first (causal_order, qattn_attn.h)
+    p.risky_lo = p.risky_hi = 0;
+    if (a.is_causal && a.precision == QATTN_PRECISION_AUTO) {
+        p.risky_lo = std::min(p.nqb, (kTwoTermKeys + kQPerWG - 2) / kQPerWG);   // blocks whose first row sees < kTwoTermKeys keys: qb < lo
+        p.risky_hi = std::min(p.nqb, 2 * p.risky_lo);
+    }
     const float sm = a.sm_scale > 0.0f ? a.sm_scale : 1.0f / sqrtf((float)a.D);
     p.sm_log2e = sm * 1.4426950408889634f;
     p.precision = a.precision;
@@ -122,6 +128,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.peak_neff = a.precision == QATTN_PRECISION_AUTO ? kPeakNeff : 0.0f;
     p.max_rescue = kMaxRescueWaves;
     p.persistent = 1;
+    p.dyn_min_rounds = kDynMinRounds;
     p.no_forecast = 0;
     p.ssq_q = a.precision == QATTN_PRECISION_AUTO ? a.ssq_q : nullptr;   // (FAST: the caller vouches for flat rows)
     p.ssq_k = p.ssq_q ? a.ssq_k : nullptr;
@@ -146,6 +153,8 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     if (getenv("QATTN_MAX_RESCUE")) p.max_rescue = atoi(getenv("QATTN_MAX_RESCUE"));
     if (getenv("QATTN_PERSISTENT")) p.persistent = atoi(getenv("QATTN_PERSISTENT"));
     if (getenv("QATTN_NO_SCHED")) p.sched = nullptr;   // static block order, rescues on the spot (round 2's behaviour)
+    if (getenv("QATTN_NO_RISKY")) p.risky_lo = p.risky_hi = 0;   // plain longest-first causal order
+    if (getenv("QATTN_DYN_MIN")) p.dyn_min_rounds = atoi(getenv("QATTN_DYN_MIN"));
     if (getenv("QATTN_NO_FORECAST")) p.no_forecast = atoi(getenv("QATTN_NO_FORECAST"));
     p.waves = !use_v2 ? kWaves : e.waves;
     p.nqb = ceil_div(a.Sq, p.waves * kQPerWave);
@@ -156,6 +165,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
         if (!dbg_dev) (void)hipMalloc(&dbg_dev, sizeof(unsigned long long) * 2 * (1 << 20));
         p.dbg_buf = dbg_dev;
         (void)hipMemsetAsync(dbg_dev, 0, sizeof(unsigned long long) * 2 * n_dbg_waves, st);
+        (void)hipMemsetAsync(dbg_dev + 3 * (1 << 19), 0, sizeof(unsigned long long) * 256 * 32 * 5, st);
     }
     if (e.variant == 4) use_v2 = false;
     if (e.causal_group > 0 && p.xcd_remap && ((a.B * a.Hq) >> 3) % e.causal_group == 0) p.causal_group = e.causal_group;
@@ -210,6 +220,45 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
                             "blocks %.0f -> %.1f blocks per CU x block = %.1f us (%.0f %% of the span)\n",
                     med(pro), med(swp), med(epi), med(tot), span, blocks, blocks / 256.0, busy, 100.0 * busy / span);
         }
+        if (printed == 3 && (p.dbg & 8) && use_v2) {   // work log of the persistent workgroups (10 ns ticks)
+            std::vector<unsigned long long> wl(256 * 32 * 5);
+            (void)hipMemcpy(wl.data(), p.dbg_buf + 3 * (1 << 19), sizeof(unsigned long long) * wl.size(), hipMemcpyDeviceToHost);
+            unsigned long long first = ~0ull, last = 0;
+            for (int g = 0; g < 256; g++) for (int r = 0; r < 32; r++) {
+                const unsigned long long* e = &wl[(g * 32 + r) * 5];
+                if (!e[0]) break;
+                first = std::min(first, e[1]); last = std::max(last, std::max(e[2], std::max(e[3], e[4])));
+            }
+            double blk = 0, resc = 0, draw = 0, lead = 0, idle = 0, max_idle = 0, max_resc = 0; int groups = 0, rounds = 0, nresc = 0;
+            std::vector<double> ends;
+            for (int g = 0; g < 256; g++) {
+                const unsigned long long* e0 = &wl[(g * 32) * 5];
+                if (!e0[0]) continue;
+                groups++;
+                lead += (e0[1] - first) * 0.01;
+                unsigned long long end = 0; double r_g = 0;
+                for (int r = 0; r < 32; r++) {
+                    const unsigned long long* e = &wl[(g * 32 + r) * 5];
+                    if (!e[0]) break;
+                    rounds++;
+                    blk += (e[2] - e[1]) * 0.01;
+                    const double rs = (e[3] - e[2]) * 0.01;
+                    if (rs > 0.5) { nresc++; }
+                    r_g += rs;
+                    draw += (e[4] - e[3]) * 0.01;
+                    end = std::max(end, e[4]);
+                }
+                resc += r_g; max_resc = std::max(max_resc, r_g);
+                const double id = (last - end) * 0.01;
+                idle += id; max_idle = std::max(max_idle, id); ends.push_back(id);
+            }
+            std::sort(ends.begin(), ends.end());
+            if (groups)
+                fprintf(stderr, "[qattn dbg] work log: span %.1f us, %d workgroups x %.2f rounds | per workgroup (mean us): start lag %.2f, blocks %.1f, "
+                                "rescues %.2f (max %.1f; %d rounds with one), draw + barrier %.2f, idle before the end %.2f (median %.2f, max %.1f)\n",
+                        (last - first) * 0.01, groups, (double)rounds / groups, lead / groups, blk / groups, resc / groups, max_resc, nresc, draw / groups,
+                        idle / groups, ends[ends.size() / 2], max_idle);
+        }
         if (printed++ == 3) {
             std::vector<unsigned long long> h(2 * n_dbg_waves);
             (void)hipMemcpy(h.data(), p.dbg_buf, sizeof(unsigned long long) * 2 * n_dbg_waves, hipMemcpyDeviceToHost);
@@ -240,7 +289,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
 bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
 #ifdef QATTN_DEV
     const DevEnv& e = dev_env();
-    if (e.variant != 2 || e.exact_exp || e.waves != 8 || e.no_q_fusion) return false;
+    if (e.variant != 2 || e.exact_exp || e.waves != 8 || e.no_q_fusion || getenv("QATTN_NO_Q_FUSION")) return false;   // (also per call: tools/ab.py variants)
 #endif
     return D == 128 && in_fmt == QATTN_FMT_BF16 && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
 }

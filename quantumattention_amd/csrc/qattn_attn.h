@@ -13,6 +13,7 @@ constexpr float kRescaleThr = 3.0f;          // log2 units: P' <= 2^(5+3) = 256 
 constexpr float kPShiftByte = 5.0f;          // byte-exponential mode: P' = P * 2^5 and a deferred-rescale threshold of 3:
 constexpr float kRescaleThrByte = 3.0f;      //   P' <= 2^8 -> byte <= 120 < 0x7e; a tighter threshold (1) made the fix-up frequent
 constexpr float kByteBias = -0.3f;           // centres the (1+m/8 >= 2^(m/8)) mantissa error of the byte exponential
+constexpr int kDynMinRounds = 24;           // non-causal launches with this many query blocks per workgroup draw them dynamically (see launch_attn_v2_chk)
 constexpr int kTwoTermKeys = 1024;           // query blocks that see fewer keys than this use hi+lo (two-term) fp8 P from the start
 // One-term rows are re-done with two-term P when R = l / p_max (the inverse of the row's largest softmax weight) ends below
 // this: the error a single e4m3-rounded weight w contributes is about w * 2^-4 * |v - O|  
@@ -72,6 +73,8 @@ struct AttnParams {
     int out_fmt;
     int xcd_remap;   // 1: each XCD gets a contiguous range of heads
     int causal_group;  // causal: heads per longest-first group within an XCD (1 = head after head)
+    int dyn_min_rounds;       // non-causal launches with at least this many blocks per workgroup use the dynamic hand-out too
+    int risky_lo, risky_hi;   // causal, AUTO: query blocks [lo, hi) of a head go FIRST (map_block); lo = hi: plain longest-first
     float sm_log2e;  // sm_scale * log2(e)
     int exact_exp;   // 1: v_exp_f32 + RNE fp8 conversion everywhere (no byte-exponential fast path)
     int precision;   // QATTN_PRECISION_*
@@ -204,21 +207,65 @@ __device__ inline unsigned pack2_f16(float a, float b) {
     return u;
 }
 
+// One float at a workgroup-uniform address through the scalar cache.  The compiler only emits scalar loads for memory it can
+// prove unwritten by the kernel; a VECTOR load of a uniform value that some path never consumes stays "pending" on its
+// register, and the next write to that register then waits for every outstanding vector-memory operation -- stores included.
+__device__ __forceinline__ float scalar_load_f32(const float* p) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is fence + barrier, and the fence drains the wave's
+// global stores too (s_waitcnt vmcnt(0)): at the end of a query block that is the write acknowledgement of the block's O rows
+// (1 - 2 us on this chip) in front of a barrier whose only job is to hand over the K/V ring, the Q slots and the vote words.
+// gfx950 backs a barrier off while memory operations are outstanding, so only the LDS counter has to be waited for.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// The few words the waves of a workgroup pass each other at the end of a block (votes, the next block's number), written and
+// read through asm: in front of every LDS access of its own the compiler waits for ALL outstanding vector-memory operations
+// (it cannot tell the access from the LDS-DMA destinations, and stores share the counter) -- right behind the O stores that
+// is their write acknowledgement again.  The K/V ring's DMA of the block has been waited for long before (kv_sweep).
+__device__ __forceinline__ unsigned lds_addr(const volatile void* p) {
+    return (unsigned)(unsigned long)(const volatile __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_write_word_raw(volatile unsigned* p, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_read_word_raw(const volatile unsigned* p) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_read_8words_raw(const volatile unsigned* p, v4i& a, v4i& b) {   // p: 16-byte aligned
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(lds_addr(p)) : "memory");
+}
+
 // v_max3_f32 through asm: on MFMA results the compiler otherwise adds a canonicalising v_max_f32 x, x, x per chain.  Interleave
 // THREE independent chains: hipcc pads wait states between an asm statement and a VALU that reads its output unless two other
 // instructions sit in between.
+// HAZARD: the compiler does NOT count the MFMA -> VALU read wait states for an operand of inline asm (it does for its own
+// instructions).  A caller that feeds MFMA results into max3_raw must know they have landed: the hand-scheduled kernel reads a
+// score tile a whole pipeline step (>= 2 later MFMAs) after the MFMAs that wrote it; everything else goes through
+// max32_after_mfma below.
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
-// the maximum of the 32 scores a lane holds of one 64-key chunk (two 32-key tiles)
-__device__ __forceinline__ float max32_raw(const v16f& s0, const v16f& s1) {
-    float a = max3_raw(s0[0], s0[1], s0[2]), b = max3_raw(s0[3], s0[4], s0[5]), c = max3_raw(s0[6], s0[7], s0[8]);
-    a = max3_raw(a, s0[9], s0[10]); b = max3_raw(b, s0[11], s0[12]); c = max3_raw(c, s0[13], s0[14]);
-    a = max3_raw(a, s0[15], s1[0]); b = max3_raw(b, s1[1], s1[2]); c = max3_raw(c, s1[3], s1[4]);
-    a = max3_raw(a, s1[5], s1[6]); b = max3_raw(b, s1[7], s1[8]); c = max3_raw(c, s1[9], s1[10]);
-    a = max3_raw(a, s1[11], s1[12]); b = max3_raw(b, s1[13], s1[14]); c = max3_raw(c, s1[15], s1[15]);
+// The maximum of the 32 scores a lane holds of one 64-key chunk (s0, then s1 = the accumulators of two QK^T MFMAs issued in this
+// order).  The first touch is a plain fmaxf on the YOUNGER tile: the compiler waits out the MFMA latency in front of it, and every
+// asm chain starts from its result, so none of them can be scheduled ahead of it.
+__device__ __forceinline__ float max32_after_mfma(const v16f& s0, const v16f& s1) {
+    const float first = fmaxf(s1[14], s1[15]);
+    float a = max3_raw(first, s0[0], s0[1]), b = max3_raw(first, s0[2], s0[3]), c = max3_raw(first, s0[4], s0[5]);
+    a = max3_raw(a, s0[6], s0[7]); b = max3_raw(b, s0[8], s0[9]); c = max3_raw(c, s0[10], s0[11]);
+    a = max3_raw(a, s0[12], s0[13]); b = max3_raw(b, s0[14], s0[15]); c = max3_raw(c, s1[0], s1[1]);
+    a = max3_raw(a, s1[2], s1[3]); b = max3_raw(b, s1[4], s1[5]); c = max3_raw(c, s1[6], s1[7]);
+    a = max3_raw(a, s1[8], s1[9]); b = max3_raw(b, s1[10], s1[11]); c = max3_raw(c, s1[12], s1[13]);
     return max3_raw(a, b, c);
 }
 
@@ -293,6 +340,20 @@ inline int xcd_count() { const int c = cu_count(); return c > 0 && c % kCusPerXc
 // blocks instead of on a late heavy one), as long as the group's K + V fit kCausalGroupBytes of the XCD's L2.
 constexpr int kCausalHeadGroup = 4;
 constexpr size_t kCausalGroupBytes = 2u << 20;
+// Causal order of a head's query blocks: longest first (LPT), except that the blocks most likely to need a rescue go before
+// everything else.  With AUTO the blocks whose first row sees fewer than kTwoTermKeys keys start in two-term mode (no rescue
+// possible), the ones just above that line (risky_lo <= qb < risky_hi: rows that see 1 .. 2 kTwoTermKeys keys) are where the
+// one-term sweep meets borderline rows -- on N(0,1) data every rescue of a causal launch falls there.  Under plain LPT those
+// short blocks come last, so their rescues (about 20 us each, a third of a long block) landed on the launch's tail, where
+// no other work is left to balance them: workgroups idled 33 us on average before the end of a C3 launch, 16 us with FAST
+// (dev work log).  Uncertain jobs first is the textbook order; the tail is then made of the cheap two-term
+// blocks.
+__device__ inline int causal_order(const AttnParams& p, int slot, int nqb) {
+    const int hi = min(p.risky_hi, nqb), lo = min(p.risky_lo, hi);   // (a permutation of 0 .. nqb - 1 for any nqb)
+    if (slot < hi - lo) return hi - 1 - slot;
+    const int s2 = slot - (hi - lo);
+    return s2 < nqb - hi ? nqb - 1 - s2 : lo - 1 - (s2 - (nqb - hi));
+}
 __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool causal, int& head, int& qb) {
     if (p.xcd_remap) {
         const int xcd = bid & 7, idx = bid >> 3, hpx = (p.B * p.Hq) >> 3;
@@ -300,7 +361,7 @@ __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool cau
         if (causal && G > 1) {
             const int per = G * nqb, grp = idx / per, r = idx % per;
             head = xcd * hpx + grp * G + r % G;
-            qb = nqb - 1 - r / G;
+            qb = causal_order(p, r / G, nqb);
             return;
         }
         head = xcd * hpx + idx / nqb;
@@ -309,7 +370,7 @@ __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool cau
         head = bid / nqb;
         qb = bid % nqb;
     }
-    if (causal) qb = nqb - 1 - qb;  // heaviest query blocks first
+    if (causal) qb = causal_order(p, qb, nqb);
 }
 
 // In-place fix-ups of a finished S^T chunk before its softmax (both rare or cheap, kept out of the hot block):

@@ -703,17 +703,22 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
 #endif
         // a wave without a peaked row stores its rows right away (under the other waves' last iterations, as in the unchecked
         // kernel); only then does it meet the others to learn whether some wave needs the workgroup's help
-        const float sv = p.sv ? p.sv[kv_head] : 1.0f;
+        const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
         if (!mine) {
             store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq);
             if (p.lse && hh == 0 && qrow < p.Sq)
                 p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
         }
-        if (lane == 0) vote[wave] = mine ? 1u : 0u;
-        __syncthreads();   // also: every wave is done with the K/V ring
+        static_assert(NW <= 8, "eight vote words");
+        if (lane == 0) lds_write_word_raw(vote + wave, mine ? 1u : 0u);
+        lds_barrier();   // also: every wave is done with the K/V ring (the O rows just stored are nobody else's business)
         unsigned flagged = 0;
+        {
+            v4i va, vb;
+            lds_read_8words_raw(vote, va, vb);
 #pragma unroll
-        for (int w = 0; w < NW; w++) flagged |= (vote[w] != 0u ? 1u : 0u) << w;
+            for (int w = 0; w < NW; w++) flagged |= ((w < 4 ? va[w & 3] : vb[w & 3]) != 0 ? 1u : 0u) << w;
+        }
         flagged = __builtin_amdgcn_readfirstlane(flagged);
         const int nf = __builtin_popcount(flagged);
         if (nf > p.max_rescue) return kPassRedo;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
@@ -722,7 +727,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     }
 
     // ---- normalise, convert, store
-    const float sv = p.sv ? p.sv[kv_head] : 1.0f;
+    const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
     const float inv = sv / l_tot;
     store_o_rows<MB>(p.out, p.out_fmt, o, inv, bh * p.Sq + qrow, hh, qrow < p.Sq);
     if (qrow < p.Sq) {
@@ -988,16 +993,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     // kept live across the block loop costs a vector register the tightest instantiations do not have (one spilled dword).
     const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int bid = blockIdx.x;
+#ifdef QATTN_DEV
+    int dbg_round = 0;
+#endif
     for (;;) {
         int tid;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
         tid |= wave_s << 6;
         asm volatile("" : "+v"(tid));
         unsigned resc;
+#ifdef QATTN_DEV
+        // work log (QATTN_V2_DBG=24): per workgroup, per round {block, start, after the block, after its rescues, after the draw}
+        unsigned long long* wlog = nullptr;
+        {
+            QATTN_PARAMS();
+            if ((p.dbg & 8) && p.dbg_buf && dbg_round < 31) wlog = p.dbg_buf + 3 * (1 << 19) + ((long)blockIdx.x * 32 + dbg_round) * 5;
+            if (wlog && threadIdx.x == 0) { wlog[0] = (unsigned long long)bid + 1; wlog[1] = __builtin_amdgcn_s_memrealtime(); }
+            ++dbg_round;
+        }
+#endif
         {
             QATTN_PARAMS();
             resc = run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p, smem, bid, tid);
         }
+#ifdef QATTN_DEV
+        if (wlog && threadIdx.x == 0) wlog[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         if constexpr (CHECK && !TOKEN && NW == 8) {
             // a few peaked 32-row groups: on the spot, while the head's K / V are in this XCD's L2 (every wave is past the vote
             // barrier, hence done with the K/V ring).  The next block is drawn afterwards: a block reserved before the rescue would
@@ -1008,6 +1029,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
                 rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16>(p, smem, tid, bid, resc);
             }
         }
+#ifdef QATTN_DEV
+        if (wlog && threadIdx.x == 0) wlog[3] = __builtin_amdgcn_s_memrealtime();
+#endif
         QATTN_PARAMS();
         int next = -1;
         if (dynamic) {
@@ -1016,12 +1040,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
                 const int nq = p.sched_nq;
                 bcast[0] = (unsigned)sched_next_block(p.sched, nq, (int)blockIdx.x & (nq - 1), p.total_blocks / nq, (int)gridDim.x / nq);
             }
-            __syncthreads();   // also: every wave has left the ring and the Q slots before the next block fills them
-            next = __builtin_amdgcn_readfirstlane((int)bcast[0]);
+            lds_barrier();   // also: every wave has left the ring and the Q slots before the next block fills them
+            next = __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast));
         } else if (!CAUSAL && bid + (int)gridDim.x < p.total_blocks) {
             next = bid + (int)gridDim.x;
-            __syncthreads();
+            lds_barrier();
         }
+#ifdef QATTN_DEV
+        if (wlog && threadIdx.x == 0) wlog[4] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (next < 0) break;
         bid = next;
     }
@@ -1037,8 +1064,12 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     const int cus = p.xcd_remap ? cu_count() & ~7 : cu_count();
     const bool persistent = p.persistent && cus >= 8 && p.total_blocks > cus;
     int grid = persistent && (!CAUSAL || p.sched) ? cus : p.total_blocks;
-    if (p.sched && persistent && CAUSAL) {
-        // dynamic hand-out: per-XCD-label counters, zeroed every call (a memset node under graph capture)
+    if (p.sched && persistent && (CAUSAL || p.total_blocks >= (long)p.dyn_min_rounds * cus)) {
+        // dynamic hand-out: per-XCD-label counters, zeroed every call (a memset node under graph capture).  Causal launches
+        // always (unequal blocks); non-causal ones when a workgroup has many rounds to go: the CUs of one chip differ by +-5 %
+        // in speed under this kernel (dev work log: finish times spread over 58 us of a 597 us C2 launch), which equal shares
+        // turn into idle time at the end.  Measured (tools/ab.py, profiles/r03/ab_dyn_noncausal.log): 32 rounds -1.6 %,
+        // 16 rounds -0.3 %, 8 rounds +0..2.5 % (a block is then too coarse a unit to even anything out).
         p.sched_nq = p.xcd_remap ? 8 : 1;
         if (hipMemsetAsync(p.sched, 0, sizeof(SchedState), st) != hipSuccess) return QATTN_ERR_LAUNCH;
     } else {

@@ -228,7 +228,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
             if (lane == 0) vote[wave] = mine ? 1u : 0u;
         }
         // ---- running max; rescale only when a row's max grew past the headroom of the shifted exponent
-        float mx = max32_raw(s0, s1);
+        float mx = max32_after_mfma(s0, s1);
         {
             auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             m_true = max3_raw(m_true, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -443,7 +443,9 @@ static int launch_rescue_head(const AttnParams& p, int fmt, int causal, int row_
 }
 
 template <int D>
-static int launch_v4_full_d(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st) {
+static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scale_mode, hipStream_t st) {
+    AttnParams p = pin;
+    p.risky_lo = p.risky_hi = 0;   // (plain longest-first: these launches cover sub-ranges of a head's blocks, and their rescues are launches of their own)
     // leading rows (a multiple of 256) that run two-term P from the start: all of them (QATTN_PRECISION_ACCURATE) or those
     // that see fewer than kTwoTermKeys keys
     const int rows_all = ceil_div(p.Sq, 256) * 256;

@@ -229,6 +229,46 @@ def test_persistent_launch_equals_one_workgroup_per_block(precision):
     assert torch.isfinite(both).all()
 
 
+@pytest.mark.parametrize("precision", ["auto", "fast"])
+def test_dynamic_hand_out_of_a_large_non_causal_launch_equals_static_shares(precision):
+    """Non-causal launches with at least kDynMinRounds = 24 query blocks per workgroup draw their blocks from the per-XCD counters
+    (csrc/qattn_attn_v2.hip launch_attn_v2_chk); smaller ones take equal static shares.  B = 8 x 32 heads x 24 blocks = 6144
+    blocks is the former, every pair of batch elements (1536 blocks = 6 rounds) the latter: same bits, every row written."""
+    torch.manual_seed(33)
+    B, H, S, D = 8, 32, 6144, 128
+    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    q[:, 3] *= 1.25
+    q[:, 5] *= 2.0
+    with qa.config.patch({"attention.precision": precision}):
+        junk = torch.full_like(q, float("nan"))
+        del junk   # (the caching allocator hands this block to the next empty_like(q): a block nobody wrote would stay NaN)
+        whole = qa.fp8_attn_func(q, k, v)
+        assert torch.isfinite(whole).all()
+        for b in range(0, B, 2):
+            assert torch.equal(whole[b:b + 2], qa.fp8_attn_func(q[b:b + 2], k[b:b + 2], v[b:b + 2])), b
+
+
+@pytest.mark.parametrize("B,H,S", [(4, 8, 4096), (2, 4, 2304), (8, 8, 1280), (1, 8, 768), (16, 16, 2048)])
+def test_causal_block_order_visits_every_block_once(B, H, S):
+    """Causal AUTO launches take a head's query blocks longest first, except that the blocks right above the two-term line go
+    before everything else (qattn_attn.h causal_order), persistent with a dynamic hand-out when there are more blocks than
+    CUs.  Whatever the order, every block is computed exactly once: no row stays unwritten, and the result agrees with the
+    ACCURATE launch (every block two-term, no rescues) within the one-term budget."""
+    torch.manual_seed(S)
+    q, k, v = (torch.randn(B, H, S, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    with qa.config.patch({"attention.precision": "accurate"}):
+        ref = qa.fp8_attn_func(q, k, v, is_causal=True)
+    for precision in ("auto", "fast"):
+        with qa.config.patch({"attention.precision": precision}):
+            junk = torch.full_like(q, float("nan"))
+            del junk
+            out = qa.fp8_attn_func(q, k, v, is_causal=True)
+        assert torch.isfinite(out).all(), precision
+        # (FAST has no budget on rows that see few keys; AUTO keeps every row within it)
+        bound = 0.02 if precision == "auto" else 0.25
+        assert (out.float() - ref.float()).abs().max().item() < bound, precision
+
+
 def test_full_size_properties_config5_shape_S16384_H40_e5m2_causal():
     """BASELINE config 5's shape and format (float8_e5m2, causal, S = 16384, 40 heads, B = 1) at full size."""
     torch.manual_seed(5)
