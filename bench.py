@@ -25,6 +25,7 @@ The JSON line also carries
   under_load / attn_under_load / joules_per_step -- socket power, cap and shader clock (rocm-smi) while the step, resp. the
                   attention launch alone, keeps the queue full;  in_kernel_clock_ghz -- s_memtime / s_memrealtime of every wave's KV sweep
                   (median), from the stamped measurement instantiation of the attention kernel after 600 back-to-back steps;
+  step_with_producer_abs_max_ms -- the step when the caller hands over the per-head abs-max of q, k, v (the abs-max launch is skipped)
   reference_bench_shape -- the reference's own benchmark grid B16 H16 S8192, D in {64,128,256}, causal and not
                   (tests/test_interface.py:95-102,141-156), through the same fp8_attn_func step;
   accuracy     -- max-abs / rmse of the step's output on a head slice of C2, C3 and C5 against fp64 SDPA (torch, on the GPU) of the
@@ -429,6 +430,21 @@ def run_rank(args):
                         line["in_kernel_sweep_cycles_per_wave"] = cyc
                     except Exception as exc:
                         print(f"[bench] in-kernel clock skipped: {exc}", file=sys.stderr)
+            # a producer of q, k, v (projection / RoPE epilogue) that already has the per-head abs-max hands them over and the
+            # abs-max launch is skipped (qattn_fp8_quant_attention_forward_ex).  Reported beside `value`, never as `value`: the
+            # synthetic inputs have no producer, their abs-max is computed here, outside the timed region.
+            if True:
+                try:
+                    amx = lambda t: t.abs().amax(dim=(2, 3)).float()
+                    aq, ak, av = amx(q), amx(k), amx(v)
+                    with qa.config.patch({"attention.fp8_format": args.fp8, "attention.precision": args.precision}):
+                        fn_p = lambda: _native.fp8_quant_attention_forward(q, k, v, is_causal=args.causal, precision=args.precision, fp8_dtype=fp8_dtype,
+                                                                           amax_q=aq, amax_k=ak, amax_v=av)
+                        for _ in range(20):
+                            fn_p()
+                        line["step_with_producer_abs_max_ms"] = event_time(fn_p, 50)
+                except Exception as exc:
+                    print(f"[bench] producer hand-off sample skipped: {exc}", file=sys.stderr)
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
             def extra(Bx, Hx, Sx, causal, fp8, n):
                 qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))

@@ -26,6 +26,7 @@ constexpr float kPeakNeff = 192.0f;
 // the e4m3 byte of P' read as e5m2 is 0.444 .. 0.5 of P'^2 over the eight mantissa values (mean 0.480); the MFMA that sums
 // it stands for kNeffByteRatio * sum P'^2
 constexpr float kNeffByteRatio = 0.472f;
+constexpr float kNeffByteLow = 0.444f;     // ... and its lower end (mantissa 100b: 1.0 / 1.5^2)
 // Which blocks START in two-term mode: those whose rows are predicted to end below kPeakR0 anyway.  For scores ~ N(0, var)
 // over n keys the row sum is about n exp(var / 2) and the largest term sits about z standard deviations out, so the smallest
 // R in a block is about n exp(var / 2 - z sqrt(var)); z (AttnParams::peak_z = 1/2 + ln(kTwoTermKeys / kPeakR0) = 4.25) makes
@@ -162,7 +163,7 @@ __device__ inline int sched_next_block(SchedState* s, int nq, int x, int bpq, in
 //     no other weight exceeds 1 / peak_r0 -- the same guarantee the R test gives an ordinary row.  On N(0,1) data nearly
 //     every row with R < 24 is one outlier key of exactly this kind (tools/sim_exact_top.py: 100 % at n = 4096, 77 % at 2048).
 template <bool BYTE, bool NEFF>
-__device__ __forceinline__ bool row_is_peaked(const AttnParams& p, float l, float l2, float r_inv_pmax, bool top_is_reference) {
+__device__ __forceinline__ bool row_is_peaked(const AttnParams& p, float l, float l2, float r_inv_pmax, bool top_is_reference, float nkeys) {
     static_assert(kPShift == 5.0f && kPShiftByte == 5.0f, "p_top below is 2^shift");
     bool peaked = l * r_inv_pmax < p.peak_r0;
     if (NEFF) {
@@ -172,6 +173,19 @@ __device__ __forceinline__ bool row_is_peaked(const AttnParams& p, float l, floa
         const float l_r = l - p_top, l2_r = fmaxf(l2 - p_top2, 0.0f);
         const bool rest_flat = top_is_reference && l_r * l_r >= p.peak_r0 * p.peak_r0 * ratio * l2_r;
         peaked = (peaked && !rest_flat) || l * l < p.peak_neff * ratio * l2;
+        // The same two guarantees for a row whose top key is exact, from the rest's moments AND the number of keys the row saw:
+        // with w2 the largest remaining weight, sum_rest w^2 >= w2^2 + (A - w2)^2 / (n - 2) (A = 1 - w_top: Cauchy-Schwarz on
+        // the n - 2 others), and the right side grows with w2 beyond A / (n - 1).  So sum_rest w^2 < t^2 + (A - t)^2 / (n - 2)
+        // with t = 1 / peak_r0 proves w2 < t; and for n > 1.5 peak_neff + 2 that bound is itself below 1 / peak_neff, the
+        // statistical budget (the exact top key adds no error to either).  The rule above (t^2 alone on the right) refuses every
+        // flat row that sees fewer than e peak_r0^2 = 1566 keys -- the band where all rescues of a flat causal launch fell.
+        // The byte estimate of sum P'^2 enters with its worst case (1 / kNeffByteLow of the e5m2 sum), not its mean.
+        static_assert(kPeakR0 * kPeakR0 == 3.0f * kPeakNeff, "the key-count floor below is 1 / (1 / neff - 1 / r0^2) + 2");
+        if (top_is_reference && peaked && nkeys > 1.5f * p.peak_neff + 2.0f) {
+            constexpr float worst = BYTE ? 1.0f / kNeffByteLow : 1.0f;
+            const float t = l / p.peak_r0, rest = l_r - t;
+            peaked = !(rest > 0.0f && worst * l2_r < t * t + rest * rest / (nkeys - 2.0f));
+        }
     }
     return peaked;
 }

@@ -688,7 +688,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     if (!TWO && check_peaked) {  // workgroup-uniform
         // R = l' / p'_max with p'_max = 2^(shift + (m_true - m_run) c): the inverse of the row's largest softmax weight
         const float r_inv_pmax = __builtin_amdgcn_exp2f(-(SHIFT + (st.m_true - m_run) * c));
-        const bool peaked = qrow < p.Sq && row_is_peaked<BYTE, NEFF>(p, l_tot, l2_tot, r_inv_pmax, st.m_true == m_run);
+        const bool peaked = qrow < p.Sq && row_is_peaked<BYTE, NEFF>(p, l_tot, l2_tot, r_inv_pmax, st.m_true == m_run, (float)(CAUSAL ? min(qrow + 1, p.Skv) : p.Skv));
 #ifdef QATTN_DEV
         if ((p.dbg & 64) && p.dbg_buf && qrow < p.Sq && hh == 0) {
             float* d = reinterpret_cast<float*>(p.dbg_buf + (1 << 19)) + (bh * p.Sq + qrow) * 4;

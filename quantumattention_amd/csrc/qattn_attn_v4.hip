@@ -333,8 +333,9 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     if (p.peak_r0 > 0.0f && !two && !only_flagged) {
         // one-term launch: a peaked row (row_is_peaked, qattn_attn.h: R = l' / p'_max and the effective key count) flags its group
         const float r_inv_pmax = __builtin_amdgcn_exp2f(-(SHIFT + (m_true - m_run) * c));
-        const bool peaked = qrow < p.Sq && (neff ? row_is_peaked<BYTE, true>(p, l_tot, l2_tot, r_inv_pmax, m_true == m_run)
-                                                 : row_is_peaked<BYTE, false>(p, l_tot, l2_tot, r_inv_pmax, false));
+        const float nkeys_row = (float)(CAUSAL ? min(qrow + 1, p.Skv) : p.Skv);
+        const bool peaked = qrow < p.Sq && (neff ? row_is_peaked<BYTE, true>(p, l_tot, l2_tot, r_inv_pmax, m_true == m_run, nkeys_row)
+                                                 : row_is_peaked<BYTE, false>(p, l_tot, l2_tot, r_inv_pmax, false, nkeys_row));
         if (__any(peaked) && lane == 0 && q0 < p.Sq) *flag = 1u;
     }
     const float sv = p.sv ? p.sv[kv_head] : 1.0f;

@@ -148,6 +148,8 @@ __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv
         const b2 h = __builtin_convertvector(q, b2);  // v_cvt_pk_bf16_f32: RNE
         unsigned u;
         __builtin_memcpy(&u, &h, 4);
+        // (the clamp is not what bounds these kernels: a build without it -- legal whenever the scale comes from the tensor's own
+        // abs-max -- quantised K and V in the same time and gained 1 % on the step, within the noise; profiles/r03/prepass_variants.md)
         unsigned mag = u & 0x7fff7fffu;
         u16x2 pm;
         __builtin_memcpy(&pm, &mag, 4);

@@ -122,12 +122,23 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
         p1 = __builtin_elementwise_max(p1, __builtin_elementwise_max(pc, pd));
         __builtin_memcpy(&m0, &p0, 4); __builtin_memcpy(&m1, &p1, 4);
         if (moments) {
+            // sum of squares, two elements per instruction: v_dot2c_f32_{bf16,f16} (fp32 accumulate).  The unpack + v_pk_fma_f32 form
+            // took 12 VALU per 16 bytes and made this HBM-bound pass VALU-bound when the moments are on (AUTO); the sums only
+            // feed the variance forecast (predicted_r), whose decision does not hang on the last bits.
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const f2 x = IN_FMT == QATTN_FMT_BF16 ? f2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)}
-                                                      : f2{load16f<IN_FMT>((unsigned short)(w[i] & 0xffffu)), load16f<IN_FMT>((unsigned short)(w[i] >> 16))};
-                ss = __builtin_elementwise_fma(x, x, ss);
+                if (IN_FMT == QATTN_FMT_BF16) {
+                    b2 x;
+                    __builtin_memcpy(&x, &w[i], 4);
+                    ss[i & 1] = __builtin_amdgcn_fdot2_f32_bf16(x, x, ss[i & 1], false);
+                } else {
+                    h2 x;
+                    __builtin_memcpy(&x, &w[i], 4);
+                    ss[i & 1] = __builtin_amdgcn_fdot2(x, x, ss[i & 1], false);
+                }
             }
         }
     };

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Model of the key-count form of the exact-top rule (qattn_attn.h row_is_peaked, round 3): for a row whose top key is the
+reference (exact), the rest is accepted when  sum_rest P'^2 < t^2 + (l_rest - t)^2 / (n - 2),  t = l / 24  -- which proves
+that no other weight exceeds 1 / 24 (Cauchy-Schwarz on the n - 2 remaining keys) and that the statistical budget 1 / 192 holds.
+Counts flagged 32-row groups of flat causal / non-causal heads under the old and the new rule, and the worst one-term error among
+the rows each accepts.   python tools/sim_exact_top_n.py"""
+import math, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from sim_heavy import E4M3_LUT, E5M2_LUT
+from sim_exact_top import ref_out
+
+def sim(q, k, v, c, causal, bias=-0.3, shift=5.0, thr=3.0, chunk=64):
+    Sq, D = q.shape; Skv = k.shape[0]
+    s_all = (q.double() @ k.double().T).float()
+    m_run = torch.full((Sq,), -1e30); m_true = torch.full((Sq,), -1e30)
+    l = torch.zeros(Sq); q2 = torch.zeros(Sq); o = torch.zeros(Sq, D, dtype=torch.float64)
+    qi = torch.arange(Sq)[:, None]
+    for k0 in range(0, Skv, chunk):
+        s = s_all[:, k0:k0 + chunk].clone()
+        if causal:
+            s = torch.where(torch.arange(k0, min(k0 + chunk, Skv))[None, :] > qi, torch.tensor(-float("inf")), s)
+        mx = s.max(1).values
+        live = mx > -1e30
+        m_true = torch.maximum(m_true, mx)
+        need = (((mx - m_run) * c > thr) & live).view(-1, 32).any(1).repeat_interleave(32)
+        m_new = torch.where(need & live, torch.maximum(m_run, mx), m_run)
+        alpha = torch.exp2((m_run - m_new) * c)
+        o *= alpha[:, None].double(); l = l * alpha; q2 = q2 * alpha * alpha
+        m_run = m_new
+        x = s * c + (shift - m_run * c)[:, None]
+        b = torch.clamp(torch.round(8.0 * x + 56.0 + bias), 0, 126)
+        b = torch.where(torch.isnan(b), torch.zeros_like(b), b).long()
+        ph = E4M3_LUT[b]
+        l = l + ph.sum(1); q2 = q2 + E5M2_LUT[b].sum(1)
+        o += ph.double() @ v[k0:k0 + chunk].double()
+    out = (o / l.double()[:, None]).float().to(torch.bfloat16).float()
+    ptop = torch.exp2(shift + (m_true - m_run) * c)
+    return out.numpy(), l.numpy(), q2.numpy(), ptop.numpy(), (m_true == m_run).numpy()
+
+def rules(l, q2, ptop, exact, n):
+    R = l / ptop
+    ratio = 1 / 0.472
+    l_r, l2_r = l - 32.0, np.maximum(q2 - 512.0, 0)
+    old = ((R < 24) & ~(exact & (l_r * l_r >= 576 * ratio * l2_r))) | (l * l < 192 * ratio * q2)
+    t = l / 24; rest = l_r - t
+    ok_n = exact & (n > 290) & (rest > 0) & (l2_r / 0.444 < t * t + rest * rest / (n - 2))
+    new = old & ~ok_n
+    return old, new
+
+if __name__ == "__main__":
+    D = 128; c0 = 1.4426950408889634 / math.sqrt(D)
+    def rnd(S, seed, a=1.0):
+        g = torch.Generator().manual_seed(seed)
+        return torch.randn(S, D, generator=g) * a, torch.randn(S, D, generator=g), torch.randn(S, D, generator=g)
+    for name, S, causal, a in (("causal S=4096", 4096, True, 1.0), ("causal S=4096 q x1.3", 4096, True, 1.3), ("full S=2048", 2048, False, 1.0), ("full S=1024", 1024, False, 1.0),
+                               ("full S=4096", 4096, False, 1.0)):
+        fo = fn = g = 0; wo = wn = 0.0
+        for h in range(12):
+            q, k, v = rnd(S, h, a)
+            out, l, q2, ptop, exact = sim(q, k, v, c0, causal)
+            err = np.abs(out - ref_out(q, k, v, c0, causal)).max(1)
+            rows = np.arange(S)
+            n = np.minimum(rows + 1, S).astype(np.float64) if causal else np.full(S, float(S))
+            keep = rows >= (1024 if causal else 0)   # (the blocks below are two-term from the start)
+            old, new = rules(l, q2, ptop, exact, n)
+            fo += (old & keep).reshape(-1, 32).any(1).sum(); fn += (new & keep).reshape(-1, 32).any(1).sum(); g += keep.reshape(-1, 32).any(1).sum()
+            wo = max(wo, err[keep & ~old].max()); wn = max(wn, err[keep & ~new].max())
+        print(f"{name}: groups {g} | old rule flags {fo} (worst accepted {wo:.4f}) | key-count rule flags {fn} (worst accepted {wn:.4f})", flush=True)
