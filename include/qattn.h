@@ -172,8 +172,8 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
  * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
- * and one write of Q.  There (and for Skv <= 16384) V is also quantised differently from qattn_quant_qkv_fp8: one power-of-two
- * scale per 64-key chunk, found inside the quantise pass (no abs-max pass over V) and applied by the kernel's PV products as
+ * and one write of Q.  There, and with head-wise scales at D = 64 / 256 (both for Skv <= 16384), V is also quantised
+ * differently from qattn_quant_qkv_fp8: one power-of-two scale per 64-key chunk, found inside the quantise pass (no abs-max pass over V) and applied by the kernel's PV products as
  * the MFMA's E8M0 block scale; v8 then holds those payloads, scale_v is written as 1.0 and the chunk scales live in the
  * workspace (oracle restatement: oracle.quantize_v_block).  Everywhere else results are bit-identical to the separate
  * calls, with one more documented exception: under
@@ -196,8 +196,8 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
  * into the caller's graph and fuses the abs-max reduction with whatever wrote q and k (nn.py:410-418).  Head-wise scales only.
  *   amax_q / amax_k / amax_v  NULL, or fp32 [B,Hq] / [B,Hkv] / [B,Hkv]: max |x| over each head of the 16-bit tensor, exactly (the
  *                             fp32 value of the largest 16-bit magnitude).  A tensor with a supplied abs-max takes no part in the
- *                             abs-max launch; with all of them supplied (amax_v is not needed where V is block-scaled: D = 128,
- *                             bf16, Skv <= 16384) the launch is skipped -- at B4 H32 S4096 D128 that is 0.05 of 0.64 ms.  The
+ *                             abs-max launch; with all of them supplied (amax_v is not needed where V is block-scaled: head-wise
+ *                             scales, Skv <= 16384, D = 64 / 256 or D = 128 from bf16 inputs) the launch is skipped -- at B4 H32 S4096 D128 that is 0.05 of 0.64 ms.  The
  *                             results are bit-identical to qattn_fp8_quant_attention_forward's.  A value LARGER than the true
  *                             abs-max is safe (a coarser scale, no clipping) but no longer the reference's scale; a smaller one clips.
  *   ssq_q / ssq_k             NULL, or fp32 [B,Hq] / [B,Hkv]: sum of x^2 over each head (both or neither).  Only read under

@@ -388,12 +388,14 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     const bool auto_head = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD;
     const bool ext_moments = auto_head && ssq_q != nullptr;
     const bool moments = auto_head && !ext_moments && !amax_q && !amax_k;
-    // block-scaled V where the hand-scheduled kernel runs (its PV products take the chunk's scale byte) and a head has at most
-    // kMomentSplits chunks: V then needs no abs-max pass
+    // block-scaled V with head-wise scales wherever the kernel's PV products take the chunk's scale byte -- the hand-scheduled
+    // D = 128 kernel in its fused-Q instantiation, the templated kernel (D = 64 / 256) -- and a head has at most kMomentSplits
+    // chunks: V then needs no abs-max pass
+    const bool vs_kernel = fuse_q || (scale_mode == QATTN_SCALE_HEAD && !attn_v2_covers(D, is_causal, scale_mode));
 #ifdef QATTN_DEV
-    const bool v_block = fuse_q && (Skv + 63) / 64 <= kMomentSplits && !getenv("QATTN_NO_VBLOCK");
+    const bool v_block = vs_kernel && (Skv + 63) / 64 <= kMomentSplits && !getenv("QATTN_NO_VBLOCK") && dev_env().variant == 2;
 #else
-    const bool v_block = fuse_q && (Skv + 63) / 64 <= kMomentSplits;
+    const bool v_block = vs_kernel && (Skv + 63) / 64 <= kMomentSplits;
 #endif
     const float* ext_amax[3] = {amax_q, amax_k, amax_v};
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,

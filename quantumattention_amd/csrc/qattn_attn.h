@@ -190,11 +190,15 @@ __device__ __forceinline__ bool row_is_peaked(const AttnParams& p, float l, floa
     return peaked;
 }
 
-// PV product with a block-scaled V: `scale_a` is the E8M0 byte (e + 127) of the V chunk in A (one value for both 32-wide K
-// blocks of every row here; profiles/r02_mfma_scale_probe.log), B = P unscaled.  VS = false: the plain product.
+// PV product with a block-scaled V: `scale_word` carries the E8M0 byte (e + 127) of the V chunk in A in byte 0 (one value for
+// both 32-wide K blocks of every row here; profiles/r02_mfma_scale_probe.log) and 127 = 2^0 for B = P in byte 1 -- the
+// instruction takes its two scales from vector registers only, op_sel picks the byte, so one register serves both (a
+// separate register holding the constant 127 cost the tightest instantiations a spill).  VS = false: the plain product.
+constexpr int kScaleWordOne = (127 << 8) | 127;   // A x 2^0, B x 2^0
+__device__ __forceinline__ int vscale_word(unsigned e8m0_byte) { return (int)((e8m0_byte & 0xffu) | (127u << 8)); }
 template <int CBSZ, int BLGP, bool VS>
-__device__ inline v16f mfma_pv(v8i a, v8i b, v16f c, int scale_a) {
-    if constexpr (VS) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, CBSZ, BLGP, 0, scale_a, 0, 127);
+__device__ inline v16f mfma_pv(v8i a, v8i b, v16f c, int scale_word) {
+    if constexpr (VS) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, CBSZ, BLGP, 0, scale_word, 1, scale_word);
     else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, CBSZ, BLGP, 0, 0, 0, 0);
 }
 
@@ -502,7 +506,7 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
         v8i vf[VB];
 #pragma unroll
         for (int m = 0; m < VB; m++) vf[m] = gload_frag(vc + (m << 11));   // in flight under the softmax
-        const int vsx = vx ? (int)vx[min(t, kVxWords - 1)] : 127;
+        const int vsx = vx ? vscale_word(vx[min(t, kVxWords - 1)]) : kScaleWordOne;   // (vx: raw bytes from global memory or ready words from LDS)
         prep_scores<CAUSAL, TOKEN>(s0, s1, p, t * 64, r0, row, hh, skt);
         float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
 #pragma unroll

@@ -90,7 +90,7 @@ struct WaveState {
     // two values that change only with m_run (fix-up branch), kept instead of re-derived every iteration (2 + 2 VALU of ~87):
     float mcv;     // the additive constant of the exponent / byte formula for the current m_run (full_step: mc)
     float lim;     // m_run + thr / c: a row's chunk max above it means P' could overflow -> fix-up
-    int vsx;       // block-scaled V: E8M0 byte of the V chunk the current iteration's PV products read (127 = 2^0)
+    int vsx;       // block-scaled V: scale word (vscale_word) of the V chunk the current iteration's PV products read
 #ifdef QATTN_DEV
     unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
     unsigned long long tlast;
@@ -613,7 +613,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     st.c = c;
     st.mcv = 0.0f;       // (the first chunk always takes the fix-up branch, which sets both)
     st.lim = -1.0e30f;
-    st.vsx = 127;   // 2^0
+    st.vsx = kScaleWordOne;
 #ifdef QATTN_DEV
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -779,7 +779,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // behind the votes for the PV products of every pass of this block; the sweep's first barrier publishes them
     unsigned* vx = vote + 16;
     if (Q16) {
-        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u;   // (vexp only when nchunks <= kVxWords)
+        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (unsigned)vscale_word((p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u);   // (vexp only when nchunks <= kVxWords)
     }
     float scale_q16 = 1.0f;
     if (Q16) {
@@ -859,7 +859,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
         scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         c = p.sm_log2e * scale_q16 * p.sk[kv_head];
-        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u;
+        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (unsigned)vscale_word((p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u);
         __syncthreads();
     } else {
         c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];

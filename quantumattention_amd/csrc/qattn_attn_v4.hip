@@ -156,6 +156,15 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     // chunk 0; if the workgroup's share of a 256-row block is going to be flagged anyway, its groups are flagged now and the
     // two-term redo launch attends them -- 2 of n chunks spent instead of all.
     unsigned* vote = reinterpret_cast<unsigned*>(smem + kStages4 * STAGE + NW * kQPerWave * D);
+    // block-scaled V (fused step, head-wise scales: the pre-pass gives every 64-key chunk of V its own power-of-two scale, one
+    // E8M0 byte per chunk in p.vexp): the head's bytes are kept in LDS behind the votes -- the loop's first barrier publishes
+    // them -- and ride into the PV products as the MFMA's A scale.  127 = 2^0 where V has one scale per head.
+    constexpr bool VS = !TOKEN;
+    unsigned* vxl = vote + 16;
+    if (VS) {
+        for (int i = tid; i < kVxWords; i += NW * 64) vxl[i] = (unsigned)vscale_word((p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u);
+    }
+    const int vx_step = (VS && p.vexp != nullptr) ? 1 : 0;   // (no table entries beyond nchunks <= kVxWords; without vexp entry 0 = 2^0)
     const bool forecast = mode == 0 && flag != nullptr && p.peak_r0 > 0.0f && n_wg >= 16 && (!CAUSAL || q0_wg >= 64);
     for (int t = 0; t < n_wg; t++) {
         // Q^T fragments do not depend on the stage: request them before the barrier so their LDS latency hides behind it
@@ -175,6 +184,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
         }
         if (t + 1 < n_wg) dma_next();
         if (t >= n_w) continue;           // causal: this wave's rows end before chunk t (it keeps the barrier / DMA cadence)
+        const int vsx = VS ? (int)vxl[t * vx_step] : kScaleWordOne;   // this chunk's V scale byte (lands under the QK^T MFMAs and the softmax)
         const unsigned char* kbuf = smem + (t & 1) * STAGE + frag_lane_off;
         const unsigned char* vbuf = kbuf + CH;
         // ---- S^T = K.Q^T
@@ -295,20 +305,20 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
             l2_run += ls2;
         }
         // ---- O^T += V^T.P^T, row sums
-        o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf0, pv, o[0]);
-        o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf1, pv, o[1]);
+        o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(vf0, pv, o[0], vsx);
+        o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(vf1, pv, o[1], vsx);
         if (!BYTE && two) {
-            o[0] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf0, pl, o[0]);
-            o[1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vf1, pl, o[1]);
+            o[0] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(vf0, pl, o[0], vsx);
+            o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(vf1, pl, o[1], vsx);
         }
 #pragma unroll
         for (int m = 2; m < MB; m += 2) {  // the remaining fragments land under the MFMAs already issued
             const v8i va = lds_read_frag(vbuf + (m << 11)), vb = lds_read_frag(vbuf + ((m + 1) << 11));
-            o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(va, pv, o[m]);
-            o[m + 1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vb, pv, o[m + 1]);
+            o[m] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(va, pv, o[m], vsx);
+            o[m + 1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(vb, pv, o[m + 1], vsx);
             if (!BYTE && two) {
-                o[m] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(va, pl, o[m]);
-                o[m + 1] = mfma_f8<V_FMT, QATTN_FMT_E4M3>(vb, pl, o[m + 1]);
+                o[m] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(va, pl, o[m], vsx);
+                o[m + 1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(vb, pl, o[m + 1], vsx);
             }
         }
         if (BYTE) lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pv, lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
@@ -351,7 +361,7 @@ static int launch_v4_one(const AttnParams& p, int row_lo, int row_hi, int mode, 
     const int qb_lo = row_lo / ROWS, qb_n = ceil_div(min(row_hi, p.Sq), ROWS) - qb_lo;
     if (qb_n <= 0) return QATTN_OK;
     const int grid = p.B * p.Hq * qb_n;
-    const size_t lds = (size_t)kStages4 * (2 * 64 * D + (TOKEN ? 256 : 0)) + (size_t)NW * kQPerWave * D + 64;  // K/V ring (+ key scales) + parked Q^T fragments + forecast votes
+    const size_t lds = (size_t)kStages4 * (2 * 64 * D + (TOKEN ? 256 : 0)) + (size_t)NW * kQPerWave * D + 64 + (TOKEN ? 0 : 4 * kVxWords);  // K/V ring (+ key scales) + parked Q^T fragments + forecast votes + V chunk scale bytes
     auto kern = attn_fwd_kernel_v4<D, FMT, FMT, CAUSAL, TOKEN, BYTE>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, qb_lo, qb_n, mode);
@@ -408,7 +418,9 @@ __global__ __launch_bounds__(512, 2) void rescue_groups_kernel(const AttnParams 
             if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
             return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
-        rescue_rows<D, 8, QK_FMT, V_FMT, CAUSAL, TOKEN>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, skt, qfrag);
+        // (block-scaled V: the chunk scale bytes straight from global memory, one word per chunk)
+        rescue_rows<D, 8, QK_FMT, V_FMT, CAUSAL, TOKEN, false, !TOKEN>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, skt, qfrag,
+                                                                       (!TOKEN && p.vexp) ? p.vexp + kv_head * p.vexp_stride : nullptr);
     }
 }
 

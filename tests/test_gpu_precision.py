@@ -17,7 +17,7 @@ import torch
 import oracle
 import quantumattention_amd as qa
 from quantumattention_amd import _native
-from tests.gpu_utils import bits16, err_stats, oracle_for_fp8_path, out_to_f32
+from tests.gpu_utils import bits16, err_stats, fused_step_uses_block_v, oracle_for_fp8_path, out_to_f32
 
 pytestmark = pytest.mark.gpu
 TOL = 2.0 ** -6
@@ -27,7 +27,7 @@ def _oracle(q, k, v, causal, fp8="e4m3"):
     fmt = oracle.FMT_E4M3 if fp8 == "e4m3" else oracle.FMT_E5M2
     q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", fmt)
     k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", fmt)
-    return oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, causal=causal, v_block=q.shape[-1] == 128)   # _run is the fused step
+    return oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, causal=causal, v_block=fused_step_uses_block_v(q.shape[-1], "head", q.dtype, k.shape[2]))   # _run is the fused step
 
 
 def _run(q, k, v, causal, precision, fp8="e4m3"):
@@ -122,8 +122,8 @@ def test_many_similar_heavy_keys(K, late, causal, D):
         assert float((held > 0.9).float().mean()) > (0.01 if late else 0.9)
     q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
     k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
-    ref_fused = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal, v_block=D == 128)
-    ref_sep = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal) if D == 128 else ref_fused
+    ref_fused = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal, v_block=fused_step_uses_block_v(D, "head", q.dtype, k.shape[2]))
+    ref_sep = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal)   # (the separate calls scale V per head)
     mx_fused = err_stats(_run(q, k, v, causal, "auto"), ref_fused)[0]
     mx_sep = err_stats(_separate_calls(q, k, v, causal, "auto"), ref_sep)[0]
     assert mx_fused < TOL and mx_sep < TOL, (K, late, causal, D, mx_fused, mx_sep, frac_r)

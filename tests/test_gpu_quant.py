@@ -140,15 +140,15 @@ def test_quant_fast_path_bit_exact_on_adversarial_bit_patterns(scaling, numerics
     np.testing.assert_array_equal(got[~nan_ref], ref8[~nan_ref])
 
 
-@pytest.mark.parametrize("fp8", ["e4m3", "e5m2"])
-def test_fused_step_block_scaled_v_is_bit_exact(fp8):
-    """The fused step (D = 128, head-wise, bf16) quantises V with one power-of-two scale per 64-key chunk inside its quantise pass
+@pytest.mark.parametrize("fp8,D", [("e4m3", 128), ("e5m2", 128), ("e4m3", 64), ("e4m3", 256), ("e5m2", 64)])
+def test_fused_step_block_scaled_v_is_bit_exact(fp8, D):
+    """The fused step with head-wise scales (D = 128 from bf16 inputs on the hand-scheduled kernel; D = 64 / 256 on the templated one) quantises V with one power-of-two scale per 64-key chunk inside its quantise pass
     (no abs-max pass over V): payload (VFRAG) and scale bytes against oracle.quantize_v_block, on ragged S, with a zero chunk, a
     huge chunk, a tiny chunk, an inf and a NaN (a chunk with a non-finite abs-max gets the scale 2^0 and must still
     take the exact conversion, so that its NaN stays a NaN byte and the rows that attend it come out non-finite)."""
     from quantumattention_amd._native import LAYOUT_KFRAG, LAYOUT_VFRAG, SCALE_HEAD, PRECISION, fmt_of, _stream
     torch.manual_seed(3)
-    B, H, S, D = 2, 3, 1000, 128
+    B, H, S = 2, 3, 1000
     q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
     v[0, 0, 64:128] = 0
     v[0, 1, 128:192] *= 3.0e4
