@@ -253,6 +253,21 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
                 idle += id; max_idle = std::max(max_idle, id); ends.push_back(id);
             }
             std::sort(ends.begin(), ends.end());
+            if (groups) {   // per XCD label (blockIdx.x & 7): mean time a workgroup spent in its blocks, mean finish time
+                char line[512]; int n = 0;
+                for (int x = 0; x < 8; x++) {
+                    double busy = 0, fin = 0; int cnt = 0;
+                    for (int g = x; g < 256; g += 8) {
+                        const unsigned long long* e0 = &wl[(g * 32) * 5];
+                        if (!e0[0]) continue;
+                        unsigned long long end = 0;
+                        for (int r = 0; r < 32; r++) { const unsigned long long* e = &wl[(g * 32 + r) * 5]; if (!e[0]) break; busy += (e[2] - e[1]) * 0.01; end = std::max(end, e[4]); }
+                        fin += (end - first) * 0.01; cnt++;
+                    }
+                    if (cnt) n += snprintf(line + n, sizeof(line) - n, " x%d %.0f/%.0f", x, busy / cnt, fin / cnt);
+                }
+                fprintf(stderr, "[qattn dbg] per XCD (mean us in blocks / mean finish):%s\n", line);
+            }
             if (groups)
                 fprintf(stderr, "[qattn dbg] work log: span %.1f us, %d workgroups x %.2f rounds | per workgroup (mean us): start lag %.2f, blocks %.1f, "
                                 "rescues %.2f (max %.1f; %d rounds with one), draw + barrier %.2f, idle before the end %.2f (median %.2f, max %.1f)\n",
