@@ -59,6 +59,19 @@ __device__ inline float sum_partials(const float* part, int n, int lane) {
     return wave_allsum(t);
 }
 
+// Both heads' sums at once, branch-free (n <= 256 = 4 words per lane, clamped indices, zeros beyond n: the same additions in the
+// same order as sum_partials): eight loads in flight and one wait instead of a wait per loop trip and per head.
+__device__ inline void sum_partials_pair(const float* pa, const float* pb, int n, int lane, float& sa, float& sb) {
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = min(lane + 64 * k, n - 1); a[k] = pa[i]; b[k] = pb[i]; }
+    float ta = 0.0f, tb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const bool in = lane + 64 * k < n; ta += in ? a[k] : 0.0f; tb += in ? b[k] : 0.0f; }
+    sa = wave_allsum(ta);
+    sb = wave_allsum(tb);
+}
+
 struct AttnParams {
     const unsigned char* q;
     const unsigned char* k;

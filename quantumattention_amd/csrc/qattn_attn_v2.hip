@@ -371,6 +371,20 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     QATTN2_STAMP(3);
 }
 
+// One stage of the K/V ring by LDS-DMA (8-wave workgroups: one 1 KiB piece of K and one of V per wave): K at byte offset koff of
+// the head, V at voff, into the ring slot at lds_off.  kv_sweep issues stages in order; block_pass issues the first kSyncEvery of
+// them itself, together with the block's other loads (first_stages_issued).
+template <int D>
+__device__ __forceinline__ void stage_dma8(const unsigned char* kg, const unsigned char* vg, unsigned koff, unsigned voff, unsigned char* smem,
+                                           unsigned lds_off, int wave, int lane) {
+    constexpr int CH = 64 * D;
+    const unsigned piece = ((unsigned)wave << 10) + ((unsigned)lane << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg + (koff + piece)),
+                                     (__attribute__((address_space(3))) void*)(smem + lds_off + (wave << 10)), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg + (voff + piece)),
+                                     (__attribute__((address_space(3))) void*)(smem + lds_off + CH + (wave << 10)), 16, 0, 0);
+}
+
 // The KV sweep of one wave.  Returns false with st.o / st.l_run / st.m_run final.
 // `forecast` (one-term byte-exponential passes under QATTN_PRECISION_AUTO): every wave measures the variance of its 32 x 64
 // scores of the first chunk and predicts the smallest R = l / p_max of its rows from it (predicted_r with kPeakZWide: 2048
@@ -383,7 +397,8 @@ template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TW
 __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q,
-                                         bool forecast = false, unsigned* vote = nullptr, const unsigned* vx = nullptr) {   // vx (VS): the V chunks' scale bytes in LDS
+                                         bool forecast = false, unsigned* vote = nullptr, const unsigned* vx = nullptr,   // vx (VS): the V chunks' scale bytes in LDS
+                                         bool first_stages_issued = false) {   // the caller has requested stages 0 .. kSyncEvery - 1 already
     constexpr int CH = 64 * D, STAGE = 2 * CH;
     const int hh = lane >> 5;
     const int T = n_wg + 2;  // iterations t = 0 .. n_wg+1 : QK(t), softmax(t-1), PV(t-2)
@@ -425,9 +440,16 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         lds_next = lds_next + STAGE == kStagesV2 * STAGE ? 0u : lds_next + STAGE;
     };
     auto dma_for = [&](int) { dma_next(); };
+    static_assert(kSyncEvery == 2, "block_pass requests two stages");
+    if (first_stages_issued) {   // (workgroup-uniform; T >= 3) the state dma_next would have left behind
+        voff = min((unsigned)CH, koff_max);
+        koff = min(voff + (unsigned)CH, koff_max);
+        lds_next = 2 * STAGE;
+    } else {
 #pragma unroll
-    for (int g = 0; g < kSyncEvery; g++)
-        if (g < T) dma_for(g);
+        for (int g = 0; g < kSyncEvery; g++)
+            if (g < T) dma_for(g);
+    }
     load_q();  // the wave's Q^T rows (global -> [quantise ->] LDS / registers) travel while the first K/V stages do
     unsigned slot_cur = 0, slot_prev = 0;
     auto sync_iter = [&](int t, bool in_step = false) __attribute__((always_inline)) -> const unsigned char* {
@@ -596,7 +618,7 @@ template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TW
 __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
                                              int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q,
-                                             const unsigned* vx = nullptr) {
+                                             const unsigned* vx = nullptr, bool first_stages_issued = false) {
     constexpr int MB = D / 32;
     const int hh = lane >> 5;
     WaveState<D, TWO, BYTE> st;
@@ -637,7 +659,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
         }
     };
     if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
-                                                                                !TWO && check_peaked, vote, vx))
+                                                                                !TWO && check_peaked, vote, vx, first_stages_issued))
         return kPassRedo;   // forecast: the block is peaked, nothing was stored
     if constexpr ((ABL & 1024) != 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -778,14 +800,42 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // fused step: the scale bytes of this head's V chunks (block-scaled V; 127 = 2^0 where V has one scale per head), kept in LDS
     // behind the votes for the PV products of every pass of this block; the sweep's first barrier publishes them
     unsigned* vx = vote + 16;
-    if (Q16) {
-        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (unsigned)vscale_word((p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u);   // (vexp only when nchunks <= kVxWords)
-    }
+    // fused step: everything the head of a block needs from memory is requested at once -- the V scale byte of this thread, the
+    // abs-max words, then the wave's 16-bit Q rows -- and waited for once.  Left where they are used (the Q rows inside the
+    // sweep's prologue) the compiler waited for each small load in turn and only then asked for Q: four memory round trips in
+    // a row at the head of every block.  (At this point the previous block's O stores are still in flight, so any wait is a
+    // vmcnt(0): one wait covers all of them, whatever their order.)
+    uint4 rawq[Q16 ? KS : 1][4];
     float scale_q16 = 1.0f;
+    constexpr bool kStagesFirst = Q16 && NW == 8;
+    if (kStagesFirst) {   // stage 0 = {K(0), V(0)}, stage 1 = {K(1), V(0)} (kv_sweep's dma_next, first two calls)
+        const unsigned koff1 = min((unsigned)CH, (unsigned)(p.nchunks - 1) * CH);
+        stage_dma8<D>(kg, vg, 0u, 0u, smem, 0u, wave, lane);
+        stage_dma8<D>(kg, vg, koff1, 0u, smem, (unsigned)STAGE, wave, lane);
+    }
     if (Q16) {
         static_assert(!Q16 || !TOKEN, "the fused Q path is head-wise");
+        // (branch-free, clamped indices: a conditional load or a loop with a run-time trip count gets its own wait)
+        const unsigned* part = p.q_amax_part + bh * p.amax_stride;
+        const unsigned* vrow = p.vexp ? p.vexp + kv_head * p.vexp_stride : part;   // (vexp only when nchunks <= kVxWords; else any readable word)
+        const int vmax = p.vexp ? p.nchunks - 1 : 0, amax_last = p.amax_n - 1;
+        static_assert(kMomentSplits <= 256, "four abs-max words per lane");
+        unsigned vxw = vrow[min(tid & (kVxWords - 1), vmax)];
+        const unsigned a0 = part[min(lane, amax_last)], a1 = part[min(lane + 64, amax_last)];
+        const unsigned a2 = part[min(lane + 128, amax_last)], a3 = part[min(lane + 192, amax_last)];
+        const bool qvalid = qrow < p.Sq;
+        const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) rawq[s][i] = qp[s * 8 + i];   // 8 elements each; the lane's 32 elements d = 64s + 32hh .. +31
+        asm volatile("" ::: "memory");   // (keeps the requests above what follows)
+        static_assert(kVxWords <= NW * 64, "one V scale word per thread");
+        if (!(p.vexp && tid < p.nchunks)) vxw = 127u;
+        if (tid < kVxWords) vx[tid] = (unsigned)vscale_word(vxw);
+        const unsigned am = max(max(a0, a1), max(a2, a3));
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        scale_q16 = make_scale(__uint_as_float(wave_allmax_u32(am)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
     }
     // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210)
@@ -800,20 +850,11 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
         const bool qvalid = qrow < p.Sq;
         if (Q16) {
             const float rinv = 1.0f / scale_q16;
-            const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
-            uint4 raw[KS][4];
-#pragma unroll
-            for (int s = 0; s < KS; s++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    raw[s][i] = qp[s * 8 + i];   // 8 elements each; the lane's 32 elements d = 64s + 32hh .. +31
-                    if (!qvalid) raw[s][i] = make_uint4(0, 0, 0, 0);
-                }
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 int2 w[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw[s][i], scale_q16, rinv);
+                for (int i = 0; i < 4; i++) w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(qvalid ? rawq[Q16 ? s : 0][i] : make_uint4(0, 0, 0, 0), scale_q16, rinv);
                 *reinterpret_cast<v4i*>(qbuf + (s << 11)) = v4i{w[0].x, w[0].y, w[1].x, w[1].y};
                 *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = v4i{w[2].x, w[2].y, w[3].x, w[3].y};
             }
@@ -832,7 +873,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
     constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
     return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO && !(ABL & 512)>(   // (ABL 512: dev timing of the statistic's cost)
-        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx);
+        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst);
 }
 
 // The rescue of a block's flagged 32-row groups as a pass of its own, run by whichever workgroup took the queue item (or by the
@@ -916,7 +957,9 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
             // (lane from the caller's opaque thread index: derived from threadIdx.x it is hoisted out of the kernel's block loop
             // as a 64-bit byte offset and spilled)
             const int lane = tid & 63, kvh = (head / p.Hq) * p.Hkv + (head % p.Hq) / (p.Hq / p.Hkv);
-            var = sum_partials(p.ssq_q + (long)head * p.ssq_stride, p.ssq_n, lane) * sum_partials(p.ssq_k + (long)kvh * p.ssq_stride, p.ssq_n, lane) * p.var_mul;
+            float sa, sb;
+            sum_partials_pair(p.ssq_q + (long)head * p.ssq_stride, p.ssq_k + (long)kvh * p.ssq_stride, p.ssq_n, lane, sa, sb);
+            var = sa * sb * p.var_mul;
             if (!(var >= kVarDeadband)) var = 1.0f;
         }
         const int nkeys = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;   // keys the block's first row attends

@@ -30,6 +30,7 @@ template <int D, bool LIGHT> struct V4Shape {
 // 4 scores -> 4 e4m3 bytes of 2^x (see byte_group in qattn_attn_v2.hip: fma x4, v_cvt_pknorm_u16_f32 x2, v_perm_b32)
 __device__ __forceinline__ int byte_exp4(float s0, float s1, float s2, float s3, float c8, float off8) {
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    // (v_pk_fma_f32 for the two pairs: 4-6 % SLOWER even at D = 64, where this kernel is VALU-bound -- profiles/r03/ab_pkfma_d64.log)
     const us2 qa = __builtin_amdgcn_cvt_pknorm_u16(__builtin_fmaf(s0, c8, off8), __builtin_fmaf(s1, c8, off8));
     const us2 qb = __builtin_amdgcn_cvt_pknorm_u16(__builtin_fmaf(s2, c8, off8), __builtin_fmaf(s3, c8, off8));
     unsigned ua, ub;
