@@ -807,7 +807,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // vmcnt(0): one wait covers all of them, whatever their order.)
     uint4 rawq[Q16 ? KS : 1][4];
     float scale_q16 = 1.0f;
-    constexpr bool kStagesFirst = Q16 && NW == 8;
+    constexpr bool kStagesFirst = NW == 8;
     if (kStagesFirst) {   // stage 0 = {K(0), V(0)}, stage 1 = {K(1), V(0)} (kv_sweep's dma_next, first two calls)
         const unsigned koff1 = min((unsigned)CH, (unsigned)(p.nchunks - 1) * CH);
         stage_dma8<D>(kg, vg, 0u, 0u, smem, 0u, wave, lane);
@@ -838,11 +838,24 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
         scale_q16 = make_scale(__uint_as_float(wave_allmax_u32(am)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
     }
-    // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210)
+    // pre-quantised Q: the lane's 32-byte pieces, requested here for the same reason
+    v4i rawq8[Q16 ? 1 : KS][2];
+    if (!Q16) {
+        const bool qvalid = qrow < p.Sq;
+        const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? qrow : 0)) * D) + hh * 32;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            rawq8[s][0] = *reinterpret_cast<const v4i*>(qp + s * 64);
+            rawq8[s][1] = *reinterpret_cast<const v4i*>(qp + s * 64 + 16);
+        }
+        asm volatile("" ::: "memory");
+    }
+    // softmax scale in the exp2 domain: c = scale_q * scale_k * sm_scale * log2(e)   (tk/attention.py:204-210); the per-head
+    // scales through the scalar cache (a vector load of a uniform value is waited for with vmcnt(0): every load above)
     float c;
     if (TOKEN) c = p.sm_log2e * (qrow < p.Sq ? p.sq[bh * p.Sq + qrow] : 1.0f);
-    else if (Q16) c = p.sm_log2e * scale_q16 * p.sk[kv_head];
-    else c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
+    else if (Q16) c = p.sm_log2e * scale_q16 * scalar_load_f32(p.sk + kv_head);
+    else c = p.sm_log2e * scalar_load_f32(p.sq + bh) * scalar_load_f32(p.sk + kv_head);
     const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
 
     // invoked by kv_sweep right after the first K/V stages have been requested, so the two latencies overlap
@@ -859,11 +872,9 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
                 *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = v4i{w[2].x, w[2].y, w[3].x, w[3].y};
             }
         } else {
-            const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? qrow : 0)) * D) + hh * 32;
 #pragma unroll
             for (int s = 0; s < KS; s++) {
-                v4i lo = *reinterpret_cast<const v4i*>(qp + s * 64);
-                v4i hi = *reinterpret_cast<const v4i*>(qp + s * 64 + 16);
+                v4i lo = rawq8[Q16 ? 0 : s][0], hi = rawq8[Q16 ? 0 : s][1];
                 if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
                 *reinterpret_cast<v4i*>(qbuf + (s << 11)) = lo;
                 *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = hi;
