@@ -401,6 +401,33 @@ def test_c_abi_error_codes_instead_of_exceptions():
         assert len(L.qattn_strerror(code)) > 0
 
 
+@pytest.mark.parametrize("causal,B,H,S", [(True, 4, 8, 4096), (False, 8, 32, 6144)])
+def test_null_workspace_runs_the_static_launch_with_the_same_bits(causal, B, H, S):
+    """include/qattn.h: the attention workspace may be NULL for FAST / ACCURATE; a causal launch then uses one workgroup per query
+    block and a large non-causal one equal static shares instead of the dynamic block hand-out -- the same results bit for bit."""
+    import ctypes
+
+    torch.manual_seed(4)
+    q, k, v = (torch.randn(B, H, S, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    q8, kf, vf, sq, sk, sv = _native.quant_qkv_fp8(q, k, v)
+    L = _native.lib()
+    need = L.qattn_attention_workspace_bytes(B, H, S)
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(with_ws):
+        out = torch.full((B, H, S, 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+        rc = L.qattn_fp8_attention_forward(P(q8), P(kf), P(vf), P(out), None, P(sq), P(sk), P(sv), B, H, H, S, S, 128, 0, 0, 2, 0, int(causal),
+                                           ctypes.c_float(0.0), 1, 0, P(ws) if with_ws else None, ctypes.c_size_t(need if with_ws else 0), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run(True), run(False)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("D,causal,fp8,dtype", [(128, False, "e4m3", torch.bfloat16), (128, True, "e5m2", torch.bfloat16),
                                                (128, False, "e4m3", torch.float16), (64, True, "e4m3", torch.bfloat16),
                                                (256, False, "e4m3", torch.bfloat16)])
