@@ -153,8 +153,8 @@ int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S
  *   is_causal keep key j <= query i (aten top-left alignment; the reference requires Sq == Skv, tests/test_interface.py:32)
  *   precision QATTN_PRECISION_*
  *   workspace device scratch of qattn_attention_workspace_bytes(B, Hq, Sq) bytes: the block hand-out counters of a causal
- *             launch, or of a non-causal one with many query blocks per CU (zeroed by the call itself, a memset node under
- *             stream capture) and one word per 32-row query group.  Needed for QATTN_PRECISION_AUTO; may be NULL otherwise,
+ *             launch, or of a non-causal one with many query blocks per CU (zeroed by the call itself with a small kernel --
+ *             graph-capture safe) and one word per 32-row query group.  Needed for QATTN_PRECISION_AUTO; may be NULL otherwise,
  *             a causal launch then uses one workgroup per query block and a large non-causal one equal static shares (a few
  *             per cent slower on long sequences; the same results bit for bit).  Nothing in it outlives the call.
  * Both GEMMs run on v_mfma_f32_32x32x64_f8f6f4; accumulation, running max/sum and the softmax are fp32.

@@ -311,6 +311,13 @@ bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
 
 }  // namespace
 
+namespace qattn {
+__global__ void zero_words_kernel(unsigned* w, long n) {   // (declared in qattn_attn.h: zero_words)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = 0u;
+}
+}  // namespace qattn
+
 extern "C" int qattn_abi_version(void) { return QATTN_ABI_VERSION; }
 
 extern "C" const char* qattn_strerror(int code) {

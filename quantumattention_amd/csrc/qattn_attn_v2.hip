@@ -1119,13 +1119,13 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     const bool persistent = p.persistent && cus >= 8 && p.total_blocks > cus;
     int grid = persistent && (!CAUSAL || p.sched) ? cus : p.total_blocks;
     if (p.sched && persistent && (CAUSAL || p.total_blocks >= (long)p.dyn_min_rounds * cus)) {
-        // dynamic hand-out: per-XCD-label counters, zeroed every call (a memset node under graph capture).  Causal launches
+        // dynamic hand-out: per-XCD-label counters, zeroed every call (by a one-block kernel: qattn_attn.h zero_words).  Causal launches
         // always (unequal blocks); non-causal ones when a workgroup has many rounds to go: the CUs of one chip differ by +-5 %
         // in speed under this kernel (dev work log: finish times spread over 58 us of a 597 us C2 launch), which equal shares
         // turn into idle time at the end.  Measured (tools/ab.py, profiles/r03/ab_dyn_noncausal.log): 32 rounds -1.6 %,
         // 16 rounds -0.3 %, 8 rounds +0..2.5 % (a block is then too coarse a unit to even anything out).
         p.sched_nq = p.xcd_remap ? 8 : 1;
-        if (hipMemsetAsync(p.sched, 0, sizeof(SchedState), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+        if (zero_words(p.sched->next, (long)(sizeof(SchedState) / sizeof(unsigned)), st) != hipSuccess) return QATTN_ERR_LAUNCH;
     } else {
         p.sched = nullptr;
     }

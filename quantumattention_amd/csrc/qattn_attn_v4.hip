@@ -471,7 +471,7 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
     const bool rescue = p.peak_r0 > 0.0f && rows_two < p.Sq;
     if (rescue) {
         if (!p.flags) return QATTN_ERR_WORKSPACE;
-        if (hipMemsetAsync(p.flags, 0, sizeof(unsigned) * (size_t)p.B * p.Hq * ceil_div(p.Sq, 32), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+        if (zero_words(p.flags, (long)p.B * p.Hq * ceil_div(p.Sq, 32), st) != hipSuccess) return QATTN_ERR_LAUNCH;
     }
     int rc = QATTN_OK;
     if (rows_two < p.Sq)

@@ -66,6 +66,31 @@ def test_peaked_rows_meet_the_stated_bound(S, D, sharp, causal):
         assert mx_fast > TOL, ("one-term P was expected to break the bound on these rows", mx_fast)
 
 
+@pytest.mark.parametrize("S,D,scaling,mult", [(1760, 128, "head-wise", 3.0), (1720, 128, "token-wise", 3.0), (4096, 128, "head-wise", 3.0),
+                                              (2048, 64, "head-wise", 3.0), (1977, 128, "token-wise", 2.0), (8192, 128, "head-wise", 3.0)])
+def test_dominant_exact_top_key_over_a_crushed_rest(S, D, scaling, mult):
+    """Found by tools/fuzz_parity.py: one key with three times the others' norm sits 8 .. 10 nats above an otherwise flat row.  It takes
+    the fix-up branch, becomes the row's exact reference, and the exact-top rule judged the row by its REST -- whose P' then lies at or
+    below e4m3's smallest normal and is crushed (errors of 0.1 .. 0.3 with one-term P).  row_is_peaked now also demands that the
+    other keys average at least kCrushMean; AUTO must meet the bound, and FAST must not (the case exercises the rule)."""
+    torch.manual_seed(S + D)
+    q, k, v = (torch.randn(1, 2, S, D) for _ in range(3))
+    k[:, :, S // 3] *= mult
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    m = "head" if scaling == "head-wise" else "token"
+    q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, m, oracle.FMT_E4M3)
+    k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, m, oracle.FMT_E4M3)
+    ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, scaling=m, v_block=fused_step_uses_block_v(D, scaling, q.dtype, S))
+    fn = qa.fp8_attn_func if scaling == "head-wise" else qa.fp8_token_wise_attn_func
+    with qa.config.patch({"attention.precision": "auto"}):
+        auto = out_to_f32(fn(q.cuda(), k.cuda(), v.cuda()))
+    with qa.config.patch({"attention.precision": "fast"}):
+        fast = out_to_f32(fn(q.cuda(), k.cuda(), v.cuda()))
+    assert err_stats(auto, ref)[0] < TOL, err_stats(auto, ref)
+    if mult >= 3.0:
+        assert err_stats(fast, ref)[0] > TOL, err_stats(fast, ref)
+
+
 def _heavy_inputs(S, D, K, late, seed, gap=9.0, H=1):
     """K keys that CARRY every row that sees them: their scores sit `gap` nats above an N(0,1) background with 0.15..0.3 nats of
     spread among themselves (tools/sim_heavy.py).  q = q0 + a u, heavy keys = a u + jitter, a^2 / sqrt(D) = gap; every

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (test infrastructure: uses the oracle): N random configurations of the fused step and of the separate
+C calls -- B, Hq / Hkv (GQA), Sq, Skv (ragged, Sq != Skv where not causal), D, causal, fp8 format, scaling, 16-bit dtype,
+precision, score spread (q x 1 .. x 3), one-outlier rows -- each checked against the fp64 oracle on the same quantised inputs
+(quantiser bit-exact, attention max-abs < 2^-6 max(1, |O| / 2, std V) for AUTO / ACCURATE).  Sizes the oracle finishes in a second or two.
+
+  python tools/fuzz_parity.py [N=120] [seed=0]      prints one line per case, a summary, exit status 1 on any failure
+"""
+import os, sys, time
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+import quantumattention_amd as qa  # noqa: E402
+from quantumattention_amd import _native  # noqa: E402
+from tests.gpu_utils import FMT, TDT, bits16, bits8, err_stats, fmt16, fused_step_uses_block_v, oracle_for_fp8_path, out_to_f32, unpack_frag  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+TOL = 2.0 ** -6
+fails = 0
+worst = {}
+t0 = time.time()
+for case in range(N):
+    D = int(rng.choice([64, 128, 128, 256]))
+    causal = bool(rng.integers(2))
+    Hkv = int(rng.choice([1, 2, 3, 4]))
+    Hq = Hkv * int(rng.choice([1, 1, 2, 4]))
+    B = int(rng.choice([1, 1, 2, 3]))
+    Skv = int(rng.choice([rng.integers(1, 130), rng.integers(130, 700), rng.integers(700, 1500), rng.integers(1500, 2600)]))
+    Sq = Skv if (causal or rng.integers(2)) else int(rng.integers(1, 1200))
+    while B * Hq * Sq * Skv > 3.0e7:       # keep the fp64 oracle to a couple of seconds
+        Skv = max(1, Skv // 2); Sq = Skv if causal else max(1, Sq // 2)
+    fp8 = str(rng.choice(["e4m3", "e4m3", "e5m2"]))
+    scaling = str(rng.choice(["head-wise", "head-wise", "token-wise"]))
+    dtype = torch.bfloat16 if rng.integers(4) else torch.float16
+    precision = str(rng.choice(["auto", "auto", "accurate", "fast"]))
+    spread = float(rng.choice([1.0, 1.0, 1.5, 2.0, 3.0]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    q = (torch.randn(B, Hq, Sq, D, generator=g) * spread).to(dtype)
+    k = torch.randn(B, Hkv, Skv, D, generator=g).to(dtype)
+    v = (torch.randn(B, Hkv, Skv, D, generator=g) * float(rng.choice([1.0, 0.05, 30.0]))).to(dtype)
+    if rng.integers(3) == 0 and Skv > 8:    # one outlier key per head
+        k[:, :, int(rng.integers(Skv))] *= 3.0
+    m = "head" if scaling == "head-wise" else "token"
+    q8, sq = oracle.quantize_fp8(bits16(q), fmt16(dtype), m, FMT[fp8])
+    k8, sk = oracle.quantize_fp8(bits16(k), fmt16(dtype), m, FMT[fp8])
+    vb = fused_step_uses_block_v(D, scaling, dtype, Skv)
+    ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal, v_block=vb)
+    ref_sep = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal) if vb else ref
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    with qa.config.patch({"attention.precision": precision, "attention.fp8_format": fp8}):
+        fn = qa.fp8_attn_func if scaling == "head-wise" else qa.fp8_token_wise_attn_func
+        fused = out_to_f32(fn(qc, kc, vc, is_causal=causal))
+    qg8, sqg = _native.quant_fp8(qc, scaling=scaling, fp8_dtype=TDT[fp8])
+    kf, skg = _native.quant_fp8(kc, scaling=scaling, fp8_dtype=TDT[fp8], layout=_native.LAYOUT_KFRAG)
+    vf, svg = _native.quant_fp8(vc, scaling="head-wise", fp8_dtype=TDT[fp8], layout=_native.LAYOUT_VFRAG)
+    sep = out_to_f32(_native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype, is_causal=causal,
+                                                    scaling=scaling, precision=precision))
+    # quantiser: bit-exact payloads and scales
+    q_ok = np.array_equal(bits8(qg8), q8) and np.array_equal(sqg.cpu().numpy(), sq) and \
+        np.array_equal(unpack_frag(bits8(kf), _native.LAYOUT_KFRAG, B, Hkv, Skv, D)[:, :, :Skv], k8) and np.array_equal(skg.cpu().numpy(), sk)
+    # the bound is absolute for N(0,1)-like V (errors are ~ eps w |v - O|): it scales with V's spread, and with |O| for the output rounding
+    tol = TOL * max(1.0, float(np.abs(ref).max()) / 2, float(v.float().std()))
+    mx_f, _ = err_stats(fused, ref)
+    mx_s, _ = err_stats(sep, ref_sep)
+    finite = bool(np.isfinite(fused).all() and np.isfinite(sep).all())
+    graded = precision != "fast"       # FAST has no bound on peaked rows / rows that see few keys
+    ok = q_ok and finite and (not graded or (mx_f < tol and mx_s < tol))
+    fails += not ok
+    key = (D, scaling, precision)
+    worst[key] = max(worst.get(key, 0.0), mx_f / tol, mx_s / tol) if graded else worst.get(key, 0.0)
+    print(f"{'ok  ' if ok else 'FAIL'} #{case:3d} B{B} Hq{Hq} Hkv{Hkv} Sq{Sq} Skv{Skv} D{D} {'causal' if causal else 'full  '} {fp8} {scaling[:5]} "
+          f"{'bf16' if dtype == torch.bfloat16 else 'fp16'} {precision:8s} q x{spread}: quant {'exact' if q_ok else 'DIFFERS'} | fused {mx_f:.4f} sep {mx_s:.4f} (tol {tol:.4f})"
+          f"{'' if finite else ' NON-FINITE'}", flush=True)
+print(f"{N} cases, {fails} failures, {time.time() - t0:.0f} s; worst error / tolerance per (D, scaling, precision):")
+for key in sorted(worst):
+    print("  ", key, f"{worst[key]:.2f}")
+sys.exit(1 if fails else 0)
