@@ -60,6 +60,17 @@ for case in range(N):
     vf, svg = _native.quant_fp8(vc, scaling="head-wise", fp8_dtype=TDT[fp8], layout=_native.LAYOUT_VFRAG)
     sep = out_to_f32(_native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype, is_causal=causal,
                                                     scaling=scaling, precision=precision))
+    # the 16-bit sibling path on the same tensors (fp64 SDPA of the 16-bit inputs; exact exponentials: 2^-7)
+    mx16 = tol16 = 0.0
+    if case % 2 == 0:
+        f16 = fmt16(dtype)
+        ref16 = oracle.attention_forward(bits16(q), bits16(k), bits16(v), f16, f16, f16, causal=causal)
+        got16 = out_to_f32(qa.attn_func(qc, kc, vc, is_causal=causal))
+        mx16, _ = err_stats(got16, ref16)
+        tol16 = 2.0 ** -7 * max(1.0, float(np.abs(ref16).max()) / 2, float(v.float().std()))
+        if not (np.isfinite(got16).all() and mx16 < tol16):
+            fails += 1
+            print(f"FAIL #{case:3d} 16-bit attn_func: {mx16:.4f} (tol {tol16:.4f})", flush=True)
     # quantiser: bit-exact payloads and scales
     q_ok = np.array_equal(bits8(qg8), q8) and np.array_equal(sqg.cpu().numpy(), sq) and \
         np.array_equal(unpack_frag(bits8(kf), _native.LAYOUT_KFRAG, B, Hkv, Skv, D)[:, :, :Skv], k8) and np.array_equal(skg.cpu().numpy(), sk)
@@ -75,7 +86,7 @@ for case in range(N):
     worst[key] = max(worst.get(key, 0.0), mx_f / tol, mx_s / tol) if graded else worst.get(key, 0.0)
     print(f"{'ok  ' if ok else 'FAIL'} #{case:3d} B{B} Hq{Hq} Hkv{Hkv} Sq{Sq} Skv{Skv} D{D} {'causal' if causal else 'full  '} {fp8} {scaling[:5]} "
           f"{'bf16' if dtype == torch.bfloat16 else 'fp16'} {precision:8s} q x{spread}: quant {'exact' if q_ok else 'DIFFERS'} | fused {mx_f:.4f} sep {mx_s:.4f} (tol {tol:.4f})"
-          f"{'' if finite else ' NON-FINITE'}", flush=True)
+          f"{'' if finite else ' NON-FINITE'}{f' | 16-bit {mx16:.4f} (tol {tol16:.4f})' if tol16 else ''}", flush=True)
 print(f"{N} cases, {fails} failures, {time.time() - t0:.0f} s; worst error / tolerance per (D, scaling, precision):")
 for key in sorted(worst):
     print("  ", key, f"{worst[key]:.2f}")
