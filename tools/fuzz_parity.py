@@ -67,7 +67,8 @@ for case in range(N):
         ref16 = oracle.attention_forward(bits16(q), bits16(k), bits16(v), f16, f16, f16, causal=causal)
         got16 = out_to_f32(qa.attn_func(qc, kc, vc, is_causal=causal))
         mx16, _ = err_stats(got16, ref16)
-        tol16 = 2.0 ** -7 * max(1.0, float(np.abs(ref16).max()) / 2, float(v.float().std()))
+        # (a bf16 output near |O| = 100 rounds by up to 0.25 on its own: the bound follows the largest output, un-halved)
+        tol16 = 2.0 ** -7 * max(1.0, float(np.abs(ref16).max()), float(v.float().std()))
         if not (np.isfinite(got16).all() and mx16 < tol16):
             fails += 1
             print(f"FAIL #{case:3d} 16-bit attn_func: {mx16:.4f} (tol {tol16:.4f})", flush=True)
