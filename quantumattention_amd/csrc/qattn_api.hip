@@ -81,6 +81,7 @@ struct AttnCall {
     int q_numerics;
     int amax_n, amax_stride;
     unsigned long long* stamps;   // measurement entry (else nullptr)
+    bool sched_zeroed;            // fused step: the pre-pass has cleared the hand-out counters (else the launch clears them itself)
 };
 
 // attention workspace = [SchedState of the hand-scheduled kernel's causal launches | one flag word per (b, h, 32-row group)]
@@ -137,6 +138,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.amax_n = a.amax_n; p.amax_stride = a.amax_stride; p.vexp_stride = kMomentSplits;
     p.var_mul = sm * sm / ((float)a.Sq * (float)a.Skv * (float)a.D);
     p.sched = (SchedState*)a.attn_ws;
+    p.sched_zeroed = a.sched_zeroed ? 1 : 0;
     p.flags = a.attn_ws ? (unsigned*)((unsigned char*)a.attn_ws + attn_ws_sched_bytes(a.B, a.Hq, a.Sq)) : nullptr;
     p.lse_stride = (long)qattn_lse_row_stride(a.Sq, a.lse_layout);
     p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
@@ -420,8 +422,12 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     const bool v_block = vs_kernel && (Skv + 63) / 64 <= kMomentSplits;
 #endif
     const float* ext_amax[3] = {amax_q, amax_k, amax_v};
+    // the hand-out counters of the attention launch (D = 128 kernel) are cleared by the quantise pass on its way: a launch of
+    // its own for 32 bytes sat between the two kernels for ~5 us
+    const bool zero_in_prepass = attn_v2_covers(D, is_causal, scale_mode);
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
-                              numerics, ws, fuse_q, moments, v_block, st, ext_amax);
+                              numerics, ws, fuse_q, moments, v_block, st, ext_amax, zero_in_prepass ? (unsigned*)attn_ws : nullptr,
+                              zero_in_prepass ? (int)(sched_bytes() / sizeof(unsigned)) : 0);
     if (rc != QATTN_OK) return rc;
     const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
     const bool q_ext = amax_q != nullptr;
@@ -431,7 +437,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, stamps};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, stamps, zero_in_prepass};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

@@ -88,6 +88,7 @@ struct AttnParams {
     int out_fmt;
     int xcd_remap;   // 1: each XCD gets a contiguous range of heads
     int causal_group;  // causal: heads per longest-first group within an XCD (1 = head after head)
+    int sched_zeroed;         // the hand-out counters were cleared by the kernel before this launch (fused step)
     int dyn_min_rounds;       // non-causal launches with at least this many blocks per workgroup use the dynamic hand-out too
     int risky_lo, risky_hi;   // causal, AUTO: query blocks [lo, hi) of a head go FIRST (map_block); lo = hi: plain longest-first
     float sm_log2e;  // sm_scale * log2(e)

@@ -1125,7 +1125,7 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
         // turn into idle time at the end.  Measured (tools/ab.py, profiles/r03/ab_dyn_noncausal.log): 32 rounds -1.6 %,
         // 16 rounds -0.3 %, 8 rounds +0..2.5 % (a block is then too coarse a unit to even anything out).
         p.sched_nq = p.xcd_remap ? 8 : 1;
-        if (zero_words(p.sched->next, (long)(sizeof(SchedState) / sizeof(unsigned)), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+        if (!p.sched_zeroed && zero_words(p.sched->next, (long)(sizeof(SchedState) / sizeof(unsigned)), st) != hipSuccess) return QATTN_ERR_LAUNCH;
     } else {
         p.sched = nullptr;
     }

@@ -95,6 +95,8 @@ struct QuantJobs {
     unsigned* vexp;       // block-scaled V (else nullptr): [G of v][kMomentSplits] E8M0 bytes, one per 64-key chunk
     int nsplit;           // abs-max-pass blocks per head = valid entries of amax_part / part per head
     int zmap[3];          // abs-max pass: blockIdx.z -> job (the tensors that still need the pass)
+    unsigned* zero_words; // quantise pass: zero_n (<= 256) words that its first block clears for the kernel that follows (else nullptr)
+    int zero_n;
 };
 
 template <int IN_FMT>
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     const int S = jb.S;
     // a block takes kQuantTilesPerBlock consecutive tiles (downwards); the next tile's rows are requested before the current one is
     // converted, so a block has loads in flight all the time instead of one latency-bound burst per 16 KiB
+    if (jobs.zero_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < jobs.zero_n) jobs.zero_words[tid] = 0u;
     const int g = jb.G - 1 - (int)blockIdx.y, tile_first = (S + 63) / 64 - 1 - (int)blockIdx.x * kQuantTilesPerBlock;
     if (g < 0 || tile_first < 0) return;
     const int layout = jb.layout;
@@ -668,6 +671,7 @@ extern "C" int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale
     if (head && (!workspace || workspace_bytes < qattn_quant_workspace_bytes(B, H, S, D, scale_mode))) return QATTN_ERR_WORKSPACE;
     QuantJobs jobs;
     jobs.vexp = nullptr;
+    jobs.zero_words = nullptr; jobs.zero_n = 0;
     jobs.nsplit = amax_splits(S, S, D);
     jobs.j[0] = QuantJob{(const uint4*)x, (uint4*)x8, scale, (unsigned*)workspace, nullptr, G, S, out_layout, head ? 0 : 1, nullptr};
     jobs.j[1] = jobs.j[2] = jobs.j[0];
@@ -765,7 +769,7 @@ extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, 
 int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                             float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt,
                             int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st,
-                            const float* const* ext_amax) {
+                            const float* const* ext_amax, unsigned* zero_words, int zero_n) {
     const int tok = scale_mode == QATTN_SCALE_TOKEN;
     const unsigned* ext[3] = {nullptr, nullptr, nullptr};
     if (ext_amax)
@@ -777,6 +781,7 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
     jobs.nsplit = amax_splits(Sq, Skv, D);
     const bool vblock = v_block && !tok && (Skv + 63) / 64 <= kMomentSplits;   // V's 256 words per head hold the chunks' scale bytes instead of abs-max words
     jobs.vexp = vblock ? ws + kMomentSplits * (nq + nk) : nullptr;
+    jobs.zero_words = zero_words; jobs.zero_n = zero_n;
     jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, ext[0], B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok,
                          moments ? part : nullptr};
     jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + kMomentSplits * nq, ext[1], B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
