@@ -26,11 +26,15 @@
 //    only while a row's weight is spread over many keys, so:
 //      - query blocks that see fewer than kTwoTermKeys keys run with P split hi + lo (two terms, 2x the PV MFMAs);
 //      - every other block runs one term and tracks two statistics per row: R = l / p_max (the inverse of the row's largest
-//        softmax weight) and the effective key count l^2 / sum P'^2.  Rows that end below peak_r0 / peak_neff are "peaked":
+//        softmax weight) and the effective key count l^2 / sum P'^2.  Rows that end below peak_r0 / peak_neff are "peaked"
+//        -- unless the top key is the row's exact reference and the REST is provably flat (row_is_peaked, qattn_attn.h), and
+//        always when the other keys average less than kCrushMean (they would sit in e4m3's subnormals):
 //        up to max_rescue 32-row groups of a block are recomputed on their own (rescue_rows: two-term, split-K over the 8
 //        waves); with more, the 256-row block repeats its sweep in two-term mode.  A block predicted to be peaked (score
 //        moments from the pre-pass, or the spread of its first chunk of scores) starts two-term or stops its one-term sweep
 //        after three chunks.  All paths live in one kernel, so a launch covers all query blocks of all heads.
+//  * launches with more blocks than CUs are persistent (one workgroup per CU); causal ones, and non-causal ones with many blocks per
+//    workgroup, draw their blocks from per-XCD counters (sched_next_block), heaviest first with the rescue-prone blocks ahead.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
