@@ -58,6 +58,15 @@ __device__ inline float round16(float x) {
     return FMT16 == QATTN_FMT_BF16 ? round_bf16(x) : round_fp16(x);
 }
 
+// 16 bytes that this kernel reads once and nobody re-reads from cache (the pre-pass's 16-bit inputs): a non-temporal load leaves
+// L2 and the Infinity Cache to the fp8 K / V the attention kernel is about to stream.  qattn_quant_qkv_fp8 -6 %, the step -1..2 %
+// (profiles/r03/ab_nt_loads.log).
+__device__ __forceinline__ uint4 load_nt(const uint4* p) {
+    typedef unsigned nt4 __attribute__((ext_vector_type(4)));
+    const nt4 t = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p));
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
+
 // two floats -> two fp8 bytes in the low (HI=false) or high (HI=true) half of `old`; RNE, no saturation (gfx950)
 template <int FMT8, bool HI>
 __device__ inline int cvt_pk_fp8(float a, float b, int old) {

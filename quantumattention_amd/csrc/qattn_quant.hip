@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
     for (; i + (kAmaxInFlight - 1) * 256 < end; i += kAmaxInFlight * 256) {
         uint4 v[kAmaxInFlight];
 #pragma unroll
-        for (int u = 0; u < kAmaxInFlight; u++) v[u] = xg[i + u * 256];
+        for (int u = 0; u < kAmaxInFlight; u++) v[u] = load_nt(&xg[i + u * 256]);
 #pragma unroll
         for (int u = 0; u < kAmaxInFlight; u++) fold(v[u]);
     }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
             const int vec = it * 256 + tid;
             const int row = tile * 64 + vec / VPR;
             dst[it] = make_uint4(0, 0, 0, 0);
-            if (row < S) dst[it] = xg[(long)row * VPR + vec % VPR];
+            if (row < S) dst[it] = load_nt(&xg[(long)row * VPR + vec % VPR]);
         }
     };
     uint4 held[ITERS];
