@@ -148,18 +148,8 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
     long i = beg + threadIdx.x;
     for (; i + (kAmaxInFlight - 1) * 256 < end; i += kAmaxInFlight * 256) {
         uint4 v[kAmaxInFlight];
-#ifdef QATTN_EXPERIMENT_K_TEMPORAL
-        if (jobs.zmap[zbase + blockIdx.z] == 1) {   // K: read again by the quantise pass right after
-#pragma unroll
-            for (int u = 0; u < kAmaxInFlight; u++) v[u] = xg[i + u * 256];
-        } else {
-#pragma unroll
-            for (int u = 0; u < kAmaxInFlight; u++) v[u] = load_nt(&xg[i + u * 256]);
-        }
-#else
 #pragma unroll
         for (int u = 0; u < kAmaxInFlight; u++) v[u] = load_nt(&xg[i + u * 256]);
-#endif
 #pragma unroll
         for (int u = 0; u < kAmaxInFlight; u++) fold(v[u]);
     }
