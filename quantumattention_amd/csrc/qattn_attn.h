@@ -352,7 +352,7 @@ __device__ __forceinline__ void store_o_rows(void* out, int out_fmt, const v16f 
             }
             // lanes 0..31: [own group j | upper half's group j] = columns 32m + 8j .. +7; lanes 32..63: the next 8 columns
             // (the exchange runs with every lane active; only the store is predicated on the row being inside the tensor)
-            // (non-temporal stores here, and non-temporal loads of the 16-bit Q rows, cost 2-6 % -- profiles/r03/ab_nt_loads.log)
+            // (non-temporal stores here cost the step 3-5 %, non-temporal loads of the 16-bit Q rows 2-3 % -- profiles/r03/ab_nt_loads.log)
             if (valid) *reinterpret_cast<v4i*>(op + (32 * m + 8 * j) * 2) = v4i{(int)a[0], (int)a[1], (int)b[0], (int)b[1]};
         }
 }
