@@ -390,7 +390,10 @@ inline int xcd_count() { const int c = cu_count(); return c > 0 && c % kCusPerXc
 // group's blocks are issued heaviest first ACROSS its heads (longest-processing-time order: the launch ends on the lightest
 // blocks instead of on a late heavy one), as long as the group's K + V fit kCausalGroupBytes of the XCD's L2.
 constexpr int kCausalHeadGroup = 4;
-constexpr size_t kCausalGroupBytes = 2u << 20;
+#ifndef QATTN_CAUSAL_GROUP_BYTES
+#define QATTN_CAUSAL_GROUP_BYTES (2u << 20)   // (a build knob for tools/ab.py variants)
+#endif
+constexpr size_t kCausalGroupBytes = QATTN_CAUSAL_GROUP_BYTES;
 // Causal order of a head's query blocks: longest first (LPT), except that the blocks most likely to need a rescue go before
 // everything else.  With AUTO the blocks whose first row sees fewer than kTwoTermKeys keys start in two-term mode (no rescue
 // possible), the ones just above that line (risky_lo <= qb < risky_hi: rows that see 1 .. 2 kTwoTermKeys keys) are where the
