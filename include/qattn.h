@@ -199,7 +199,10 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
  *                             fp32 value of the largest 16-bit magnitude).  A tensor with a supplied abs-max takes no part in the
  *                             abs-max launch; with all of them supplied (amax_v is not needed where V is block-scaled: head-wise
  *                             scales, Skv <= 16384, D = 64 / 256 or D = 128 from bf16 inputs) the launch is skipped -- at B4 H32 S4096 D128 that is 0.05 of 0.64 ms.  The
- *                             results are bit-identical to qattn_fp8_quant_attention_forward's.  A value LARGER than the true
+ *                             results are bit-identical to qattn_fp8_quant_attention_forward's -- under QATTN_PRECISION_AUTO when
+ *                             ssq_q / ssq_k come along (below); without them and without the abs-max pass the kernel has no
+ *                             score-spread estimate, heads with a wide spread start one-term as in the separate calls: the same
+ *                             bound, other bits.  A value LARGER than the true
  *                             abs-max is safe (a coarser scale, no clipping) but no longer the reference's scale; a smaller one clips.
  *   ssq_q / ssq_k             NULL, or fp32 [B,Hq] / [B,Hkv]: sum of x^2 over each head (both or neither).  Only read under
  *                             QATTN_PRECISION_AUTO, where the pre-pass otherwise accumulates them for the score-spread estimate

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Randomised launch-structure sweep (no oracle needed): shapes large enough for the persistent / dynamic launches of the D = 128
 kernel and for the multi-launch paths of the templated one -- B x Hq not a multiple of 8 (no XCD map), GQA, odd block counts,
-ragged lengths, causal and not, every precision, head- and token-wise -- each checked three ways:
+ragged lengths, causal and not, every precision, head- and token-wise -- each checked four ways:
   1. every output element is written (the output buffer is poisoned with NaN first, through the allocator);
   2. the batched call equals the calls on single batch elements bit for bit (those take the small-launch paths);
-  3. a HIP graph of the call, replayed twice on new data, equals the eager call bit for bit.
+  3. a HIP graph of the call, replayed twice on new data, equals the eager call bit for bit;
+  4. (head-wise) the call with the caller-supplied exact per-head abs-max of q and k equals the plain call bit for bit.
   python tools/fuzz_launch.py [N=40] [seed=0]"""
 import os, sys, time
 import numpy as np
@@ -48,6 +49,17 @@ for case in range(N):
             if not torch.equal(whole[b:b + 1], fn(q[b:b + 1], k[b:b + 1], v[b:b + 1], is_causal=causal)):
                 msg.append(f"batch element {b} differs from its own call")
                 break
+        if scaling == "head-wise" and case % 2 == 1:   # producer hand-off: the exact per-head abs-max supplied by the caller
+            # (under AUTO the sums of squares as well: without them the kernel has no score-spread estimate and wide heads start
+            #  one-term -- the same bound, other bits; the fp32 sums differ from the pass's partial sums in the last bits, which
+            #  only matters for a head exactly on the dead band's edge)
+            from quantumattention_amd import _native
+            aq, ak = q.abs().amax(dim=(2, 3)).float(), k.abs().amax(dim=(2, 3)).float()
+            extra = dict(ssq_q=(q.float() ** 2).sum(dim=(2, 3)), ssq_k=(k.float() ** 2).sum(dim=(2, 3))) if precision == "auto" else {}
+            got = _native.fp8_quant_attention_forward(q, k, v, is_causal=causal, precision=precision, fp8_dtype=_native.FP8_DTYPE[fp8],
+                                                      amax_q=aq, amax_k=ak, **extra)
+            if not torch.equal(whole, got):
+                msg.append("call with producer-supplied abs-max (and sums of squares) differs")
         if case % 3 == 0:   # graph capture + two replays on new data
             side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
