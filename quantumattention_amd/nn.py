@@ -308,7 +308,8 @@ def attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False,
 
 
 def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None,
-                           scale_q=None, scale_k=None, scaling_method=None, amax_q=None, amax_k=None) -> Tensor:
+                           scale_q=None, scale_k=None, scaling_method=None, amax_q=None, amax_k=None, ssq_q=None,
+                           ssq_k=None) -> Tensor:
     """nn.py:394-430."""
     if (scale_q is None) != (scale_k is None):
         raise ValueError("scale_q and scale_k must be both provided or both not provided")
@@ -318,12 +319,15 @@ def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_
             raise ValueError(f"Unsupported scaling_method: {scaling_method}")
         if query.dtype in _FP8_DTYPES:
             raise ValueError("fp8 query/key need scale_q and scale_k")
-        if (amax_q is not None or amax_k is not None) and scaling_method != "head-wise":
-            raise ValueError("amax_q / amax_k are per-head figures: head-wise scaling only")
+        given = [t is not None for t in (amax_q, amax_k, ssq_q, ssq_k)]
+        if any(given) and scaling_method != "head-wise":
+            raise ValueError("amax_q / amax_k / ssq_q / ssq_k are per-head figures: head-wise scaling only")
+        if (ssq_q is None) != (ssq_k is None):
+            raise ValueError("ssq_q and ssq_k must be both provided or both not provided")
         return ops.fp8_quant_attention_forward(
             query, key, value, is_causal, scaling_method, _cfg("fp8_format"),
-            _cfg("quant_numerics"), _cfg("precision"), amax_q, amax_k, scale=scale)
-    if amax_q is not None or amax_k is not None:
+            _cfg("quant_numerics"), _cfg("precision"), amax_q, amax_k, ssq_q, ssq_k, scale=scale)
+    if any(t is not None for t in (amax_q, amax_k, ssq_q, ssq_k)):
         raise ValueError("amax_q / amax_k describe 16-bit query / key; fp8 query / key come with scale_q / scale_k")
     return ops.fp8_attention_forward(
         query, key, value, scale_q, scale_k, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal,
@@ -347,10 +351,12 @@ def _fp8_attention_eager(query, key, value, is_causal, scale, scale_q, scale_k, 
 
 
 def fp8_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None, scale_q=None,
-                  scale_k=None, scaling_method=None, amax_q=None, amax_k=None) -> Tensor:
+                  scale_k=None, scaling_method=None, amax_q=None, amax_k=None, ssq_q=None, ssq_k=None) -> Tensor:
     """nn.py:433-539: validate (ValueError(reason) when unsupported), then run the wrapper.
     amax_q / amax_k (build extension, keyword-only): fp32 [B,H] per-head max |x| of 16-bit query / key from their producer --
-    the quant pre-pass then skips its abs-max launch (the reference's Inductor fusion, nn.py:410-418)."""
+    the quant pre-pass then skips its abs-max launch (the reference's Inductor fusion, nn.py:410-418).
+    ssq_q / ssq_k (both or neither): fp32 [B,H] per-head sums of squares; with precision="auto" they stand in for the moments the
+    skipped pass would have collected (without them heads with a wide score spread start one-term: same bound, other bits)."""
     supported, reason = can_use_attention(
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
         scaling_method=scaling_method, scale_q=scale_q, scale_k=scale_k)
@@ -365,4 +371,4 @@ def fp8_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=Fa
         return _fp8_attention_eager(query, key, value, is_causal, scale, scale_q, scale_k, scaling_method)   # (recomputes the abs-max itself)
     return _fp8_attention_wrapper(
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
-        scale_q=scale_q, scale_k=scale_k, scaling_method=scaling_method, amax_q=amax_q, amax_k=amax_k)
+        scale_q=scale_q, scale_k=scale_k, scaling_method=scaling_method, amax_q=amax_q, amax_k=amax_k, ssq_q=ssq_q, ssq_k=ssq_k)

@@ -122,6 +122,8 @@ def fp8_quant_attention_forward(
     precision: str = "auto",
     amax_q: Optional[torch.Tensor] = None,
     amax_k: Optional[torch.Tensor] = None,
+    ssq_q: Optional[torch.Tensor] = None,
+    ssq_k: Optional[torch.Tensor] = None,
     *,
     scale: Optional[float] = None,
 ) -> torch.Tensor:
@@ -129,15 +131,17 @@ def fp8_quant_attention_forward(
     fragment layouts, then the attention kernel runs -- what `_fp8_attention_wrapper` (nn.py:394-430) does in the
     reference through Inductor, without the intermediate row-major K copy.  amax_q / amax_k (fp32 [B,H], head-wise only):
     per-head max |x| of query / key from the kernel that produced them; the abs-max launch then has nothing to read --
-    the hand-off the reference gets from Inductor fusing the quantiser into the producer."""
+    the hand-off the reference gets from Inductor fusing the quantiser into the producer.  ssq_q / ssq_k (fp32 [B,H], both or
+    neither): per-head sums of squares, which keep precision="auto" its score-spread estimate when the abs-max pass is skipped."""
     return _native.fp8_quant_attention_forward(
         query, key, value, is_causal=is_causal, scaling=scaling_method, fp8_dtype=_native.FP8_DTYPE[fp8_format],
-        numerics=numerics, sm_scale=0.0 if scale is None else float(scale), precision=precision, amax_q=amax_q, amax_k=amax_k)
+        numerics=numerics, sm_scale=0.0 if scale is None else float(scale), precision=precision, amax_q=amax_q, amax_k=amax_k,
+        ssq_q=ssq_q, ssq_k=ssq_k)
 
 
 @_register_fake("quantumattention_amd::fp8_quant_attention_forward")
 def _(query, key, value, is_causal=False, scaling_method="head-wise", fp8_format="e4m3", numerics="compiled",
-      precision="auto", amax_q=None, amax_k=None, *, scale=None):
+      precision="auto", amax_q=None, amax_k=None, ssq_q=None, ssq_k=None, *, scale=None):
     return _out_like(query, value)
 
 

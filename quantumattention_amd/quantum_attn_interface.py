@@ -50,12 +50,14 @@ def attn_func_with_fallback(query, key, value, attn_mask=None, dropout_p=0.0, is
 
 
 def fp8_attn_func(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None, scale_q=None,
-                  scale_k=None, scaling_method: Optional[str] = None, amax_q=None, amax_k=None) -> torch.Tensor:
-    """quantum_attn_interface.py:101-127, plus amax_q / amax_k (keyword-only, optional): see nn.fp8_attention."""
+                  scale_k=None, scaling_method: Optional[str] = None, amax_q=None, amax_k=None, ssq_q=None,
+                  ssq_k=None) -> torch.Tensor:
+    """quantum_attn_interface.py:101-127, plus amax_q / amax_k / ssq_q / ssq_k (keyword-only, optional): see nn.fp8_attention."""
     if scaling_method is None:
         scaling_method = "head-wise"
     return fp8_attention(query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal,
-                         scale=scale, scale_q=scale_q, scale_k=scale_k, scaling_method=scaling_method, amax_q=amax_q, amax_k=amax_k)
+                         scale=scale, scale_q=scale_q, scale_k=scale_k, scaling_method=scaling_method, amax_q=amax_q, amax_k=amax_k,
+                         ssq_q=ssq_q, ssq_k=ssq_k)
 
 
 @_define_composite_implicit_autograd_op(

@@ -71,9 +71,9 @@ def test_public_names_and_signatures_mirror_the_reference():
     sdpa = ["query", "key", "value", "attn_mask", "dropout_p", "is_causal", "scale"]
     assert list(inspect.signature(qa.attn_func).parameters) == sdpa                                   # interface.py:41-50
     # :101-113, followed by this build's keyword-only extension (the producer-side abs-max hand-off)
-    assert list(inspect.signature(qa.fp8_attn_func).parameters) == sdpa + ["scale_q", "scale_k", "scaling_method", "amax_q", "amax_k"]
+    assert list(inspect.signature(qa.fp8_attn_func).parameters) == sdpa + ["scale_q", "scale_k", "scaling_method", "amax_q", "amax_k", "ssq_q", "ssq_k"]
     assert all(inspect.signature(qa.fp8_attn_func).parameters[n].kind is inspect.Parameter.KEYWORD_ONLY and
-               inspect.signature(qa.fp8_attn_func).parameters[n].default is None for n in ("amax_q", "amax_k"))
+               inspect.signature(qa.fp8_attn_func).parameters[n].default is None for n in ("amax_q", "amax_k", "ssq_q", "ssq_k"))
     assert list(inspect.signature(qa.fp8_token_wise_attn_func).parameters) == sdpa + ["scale_q", "scale_k"]         # :179-190
     assert list(inspect.signature(qa.nn.can_use_attention).parameters)[:8] == sdpa + ["scaling_method"]  # nn.py:282-292
     for flag in ("skip_supported_check", "force_eager_fallback"):                                   # config.py:27-28

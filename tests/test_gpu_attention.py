@@ -454,6 +454,10 @@ def test_producer_supplied_abs_max_is_bit_identical(D, causal, fp8, dtype):
         assert torch.equal(got, base), sorted(extra)
     if fp8 == "e4m3":   # ... and through the reference-shaped interface (keyword-only extension of fp8_attn_func)
         assert torch.equal(qa.fp8_attn_func(q, k, v, is_causal=causal, amax_q=aq, amax_k=ak), qa.fp8_attn_func(q, k, v, is_causal=causal))
+        assert torch.equal(qa.fp8_attn_func(q, k, v, is_causal=causal, amax_q=aq, amax_k=ak, ssq_q=ssq(q), ssq_k=ssq(k)),
+                           qa.fp8_attn_func(q, k, v, is_causal=causal))
+        with pytest.raises(ValueError):
+            qa.fp8_attn_func(q, k, v, is_causal=causal, amax_q=aq, amax_k=ak, ssq_q=ssq(q))     # both or neither
     # an upper bound instead of the exact abs-max is safe (a coarser scale, no clipping): other bits, the same attention
     loose = _native.fp8_quant_attention_forward(q, k, v, **kw, amax_q=aq * 1.5, amax_k=ak * 1.5)
     assert not torch.equal(loose, base) and torch.isfinite(loose).all()

@@ -53,11 +53,9 @@ for case in range(N):
             # (under AUTO the sums of squares as well: without them the kernel has no score-spread estimate and wide heads start
             #  one-term -- the same bound, other bits; the fp32 sums differ from the pass's partial sums in the last bits, which
             #  only matters for a head exactly on the dead band's edge)
-            from quantumattention_amd import _native
             aq, ak = q.abs().amax(dim=(2, 3)).float(), k.abs().amax(dim=(2, 3)).float()
             extra = dict(ssq_q=(q.float() ** 2).sum(dim=(2, 3)), ssq_k=(k.float() ** 2).sum(dim=(2, 3))) if precision == "auto" else {}
-            got = _native.fp8_quant_attention_forward(q, k, v, is_causal=causal, precision=precision, fp8_dtype=_native.FP8_DTYPE[fp8],
-                                                      amax_q=aq, amax_k=ak, **extra)
+            got = fn(q, k, v, is_causal=causal, amax_q=aq, amax_k=ak, **extra)   # (the keyword form of the reference-shaped interface)
             if not torch.equal(whole, got):
                 msg.append("call with producer-supplied abs-max (and sums of squares) differs")
         if case % 3 == 0:   # graph capture + two replays on new data
