@@ -145,34 +145,73 @@ def smi_read(smi, source):
             "sclk_mhz": grab(r"sclk clock level: \S+ \(([0-9.]+)Mhz\)"), "source": source}
 
 
-def accuracy_vs_16bit_v(torch, _native, q, k, v, out, causal, fp8, rows):
-    """max-abs / rmse of out[0, 0, rows] against fp64 SDPA (torch, on the GPU) of the library's own quantised q, k of that head
-    with (a) the original 16-bit V -- what the reference computes, it never quantises V -- and (b) V quantised per head."""
+def block_scaled_v(torch, v_head, fp8_dtype):
+    """The fused step's V as the PV products see it, restated in torch (csrc/qattn_common.h vblock_exponent; the oracle's
+    restatement oracle.quantize_v_block is test infrastructure and is not imported here): every 64-key chunk of a head is divided
+    by the power of two 2^e, e the smallest exponent with amax / 2^e <= fmax -- integer arithmetic on the fp32 bits of the chunk's
+    abs-max --, RNE-converted to fp8 and multiplied back.  v_head: [S, D] 16-bit; returns fp64 [S, D]."""
+    S, D = v_head.shape
+    nch = (S + 63) // 64
+    pad = torch.zeros((nch * 64, D), dtype=torch.float32, device=v_head.device)
+    pad[:S] = v_head.float()
+    ch = pad.view(nch, 64 * D)
+    bits = ch.abs().amax(dim=1).view(torch.int32).long()
+    ef = (bits >> 23) & 255
+    e4 = fp8_dtype == torch.float8_e4m3fn
+    e = ef - 127 - (8 if e4 else 15) + ((bits & 0x7FFFFF) > 0x600000).long()
+    e = torch.where((ef == 0) | (ef == 255), torch.zeros_like(e), e).clamp(-126, 126)
+    scale = torch.ldexp(torch.ones_like(e, dtype=torch.float32), e.to(torch.int32))[:, None]
+    fmax = 448.0 if e4 else 57344.0
+    deq = (ch / scale).clamp(-fmax, fmax).to(fp8_dtype).float() * scale
+    return deq.view(nch * 64, D)[:S].double()
+
+
+TWO_TERM_KEYS = 1024   # csrc/qattn_attn.h kTwoTermKeys: query blocks (256 rows) whose first row sees fewer keys attend the 16-bit V
+
+
+def accuracy_of_step(torch, _native, q, k, v, out, causal, fp8, rows, head=0):
+    """max-abs / rmse of out[0, head, rows] against fp64 SDPA (torch, on the GPU) of the library's own quantised q, k of that head with
+      * `oracle`: the V the step REALLY used -- block-scaled fp8 V (block_scaled_v above), and the original 16-bit V for the query
+        blocks that see fewer than 1024 keys (early causal rows: the reference's own PV numerics, tk/attention.py:72,286,318).  This is
+        the parity number of BASELINE.json's north_star; bound 2^-6 * max(1, |O|max / 2);
+      * `16bitV`: the original 16-bit V everywhere -- the distance to what the reference's kernel computes (it never quantises V)."""
     fp8_dtype = _native.FP8_DTYPE[fp8]
     D = q.shape[-1]
-    q8, sq = _native.quant_fp8(q[:1, :1].contiguous(), fp8_dtype=fp8_dtype)
-    k8, sk = _native.quant_fp8(k[:1, :1].contiguous(), fp8_dtype=fp8_dtype)
-    v8, sv = _native.quant_fp8(v[:1, :1].contiguous(), fp8_dtype=fp8_dtype)
+    S = q.shape[2]
+    q8, sq = _native.quant_fp8(q[:1, head:head + 1].contiguous(), fp8_dtype=fp8_dtype)
+    k8, sk = _native.quant_fp8(k[:1, head:head + 1].contiguous(), fp8_dtype=fp8_dtype)
     qd = q8[0, 0].float().double() * float(sq[0, 0])
     kd = k8[0, 0].float().double() * float(sk[0, 0])
-    vd16 = v[0, 0].double()
-    vd8 = v8[0, 0].float().double() * float(sv[0, 0])
-    got = out[0, 0].double()
-    worst = {"max_abs_vs_16bitV": 0.0, "max_abs_vs_quantisedV": 0.0}
-    se, n = 0.0, 0
+    vd16 = v[0, head].double()
+    vdb = block_scaled_v(torch, v[0, head], fp8_dtype)
+    got = out[0, head].double()
+    worst = {"max_abs_vs_oracle": 0.0, "max_abs_vs_16bitV": 0.0}
+    se, se_o, n, omax = 0.0, 0.0, 0, 0.0
     for r0 in rows:
-        r1 = min(r0 + 1024, q.shape[2])
+        r1 = min(r0 + 1024, S)
         sc = (qd[r0:r1] @ kd.T) / D ** 0.5
+        rid = torch.arange(r0, r1, device=sc.device)
         if causal:
-            sc = sc.masked_fill(torch.arange(k.shape[2], device=sc.device)[None, :] > torch.arange(r0, r1, device=sc.device)[:, None], float("-inf"))
+            sc = sc.masked_fill(torch.arange(k.shape[2], device=sc.device)[None, :] > rid[:, None], float("-inf"))
         pm = torch.softmax(sc, dim=1)
-        d16 = (got[r0:r1] - pm @ vd16).abs()
+        o16, ob = pm @ vd16, pm @ vdb
+        # rows of query blocks whose FIRST row sees < 1024 keys run the 16-bit-V pass (causal: block b sees 256 b + 1 keys; else Skv)
+        early = ((rid // 256) * 256 + 1 < TWO_TERM_KEYS) if causal else torch.full_like(rid, k.shape[2] < TWO_TERM_KEYS, dtype=torch.bool)
+        oref = torch.where(early[:, None] & bool(V16_EARLY_ROWS), o16, ob)
+        d16, dor = (got[r0:r1] - o16).abs(), (got[r0:r1] - oref).abs()
         worst["max_abs_vs_16bitV"] = max(worst["max_abs_vs_16bitV"], float(d16.max()))
-        worst["max_abs_vs_quantisedV"] = max(worst["max_abs_vs_quantisedV"], float((got[r0:r1] - pm @ vd8).abs().max()))
-        se += float((d16 ** 2).sum()); n += d16.numel()
+        worst["max_abs_vs_oracle"] = max(worst["max_abs_vs_oracle"], float(dor.max()))
+        omax = max(omax, float(oref.abs().max()))
+        se += float((d16 ** 2).sum()); se_o += float((dor ** 2).sum()); n += d16.numel()
     worst["rmse_vs_16bitV"] = (se / n) ** 0.5
-    worst["slice"] = f"batch 0, head 0, rows {[(r, min(r + 1024, q.shape[2])) for r in rows]}"
+    worst["rmse_vs_oracle"] = (se_o / n) ** 0.5
+    worst["oracle_bound"] = 2.0 ** -6 * max(1.0, omax / 2.0)
+    worst["within_bound"] = worst["max_abs_vs_oracle"] < worst["oracle_bound"]
+    worst["slice"] = f"batch 0, head {head}, rows {[(r, min(r + 1024, S)) for r in rows]}"
     return worst
+
+
+V16_EARLY_ROWS = False   # the early-row pass attends the original 16-bit V (set when the library does, see DESIGN.md section 4.6)
 
 
 def kernel_label(D, fp8, causal, fused_q):
@@ -373,6 +412,17 @@ def run_rank(args):
                          "frac": achieved / FP8_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source},
         })
         if world == 1 and not args.no_extras:
+            # what a bare fp8 MFMA loop sustains on THIS device on random operands (qattn_mfma_probe, ~0.3 s): the chip lowers its clock
+            # under dense matrix work, so the attainable rate is below the nominal 5 PFLOP/s by a device- and data-dependent factor
+            try:
+                pk = _native.measure_mfma_peak(seconds=0.3)
+                line["roofline"]["practical_peak"] = pk["TFLOPs"]
+                line["roofline"]["practical_peak_clock_ghz"] = pk["in_kernel_clock_ghz"]
+                line["roofline"]["frac_of_practical_peak"] = achieved / pk["TFLOPs"]
+                line["roofline"]["practical_peak_source"] = ("qattn_mfma_probe: bare v_mfma_f32_32x32x64_f8f6f4 loop, " + pk["operands"] +
+                                                             f", 2 waves/SIMD on every CU, {pk['launches']} launches of {pk['ms_per_launch']:.2f} ms, this run")
+            except Exception as exc:
+                print(f"[bench] practical-peak probe skipped: {exc}", file=sys.stderr)
             with qa.config.patch(cfg):
                 # sustained rate: >= 2 s of back-to-back steps, median of 20-step windows between HIP events (no host
                 # wait inside the run: the events are read after the last window)
@@ -445,6 +495,39 @@ def run_rank(args):
                         line["step_with_producer_abs_max_ms"] = event_time(fn_p, 50)
                 except Exception as exc:
                     print(f"[bench] producer hand-off sample skipped: {exc}", file=sys.stderr)
+            # context on the same box (the reference's benchmark prints FlashAttention / cuDNN SDPA beside its own number,
+            # tests/test_interface.py:127-138): PyTorch-ROCm's F.scaled_dot_product_attention and this build's own 16-bit attn_func
+            # on the same bf16 q, k, v.  Never `value`.
+            ctx = {}
+            try:
+                import torch.nn.functional as F
+
+                ctx["torch_sdpa_bf16_ms"] = event_time(lambda: F.scaled_dot_product_attention(q, k, v, is_causal=args.causal), 20)
+                ctx["torch_sdpa_bf16_TFLOPs"] = f_gpu / (ctx["torch_sdpa_bf16_ms"] * 1e-3) / 1e12
+            except Exception as exc:
+                print(f"[bench] torch SDPA sample skipped: {exc}", file=sys.stderr)
+            try:
+                ctx["attn_func_16bit_ms"] = event_time(lambda: qa.attn_func(q, k, v, is_causal=args.causal), 20)
+                ctx["attn_func_16bit_TFLOPs"] = f_gpu / (ctx["attn_func_16bit_ms"] * 1e-3) / 1e12
+            except Exception as exc:
+                print(f"[bench] attn_func sample skipped: {exc}", file=sys.stderr)
+            ctx["note"] = f"same box, same bf16 inputs, torch {torch.__version__}; the fp8 step is `ms_per_step`"
+            line["same_box_context"] = ctx
+            # non-flat score distributions (trained heads are not N(0,1)): the C2 shape with q scaled so that the score spread is 1.3 / 2
+            # -- from a spread of ~1.2 on `auto` runs the reference-precision pass for nearly every block
+            if (B, H, S, D) == (4, 32, 4096, 128) and not args.causal:
+                for tag, mul in (("c2_wide_q1p3", 1.3), ("c2_wide_q2", 2.0)):
+                    qw = (q.float() * mul).to(torch.bfloat16)
+                    fn = lambda: qa.fp8_attn_func(qw, k, v, is_causal=False)
+                    with qa.config.patch(cfg):
+                        ms = event_time(fn, 20)
+                        ams = attn_in_step(fn, 10)
+                        acc_w = accuracy_of_step(torch, _native, qw, k, v, fn(), False, args.fp8, [0, 3072])
+                    line[tag] = {"ms_per_step": ms, "attn_kernel_ms": ams, "step_TFLOPs": f_gpu / (ms * 1e-3) / 1e12,
+                                 "attn_frac_of_peak": None if not ams else f_gpu / (ams * 1e-3) / 1e12 / FP8_PEAK_TFLOPS,
+                                 "max_abs_vs_oracle": acc_w["max_abs_vs_oracle"], "oracle_bound": acc_w["oracle_bound"],
+                                 "max_abs_vs_16bitV": acc_w["max_abs_vs_16bitV"], "q_multiplier": mul}
+                    del qw
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
             def extra(Bx, Hx, Sx, causal, fp8, n):
                 qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
@@ -478,14 +561,16 @@ def run_rank(args):
                 # distance to the reference's own semantics (V and P stay 16-bit there), per config, on a head slice
                 acc = {}
                 with qa.config.patch({"attention.fp8_format": "e4m3", "attention.precision": args.precision}):
-                    acc["c2"] = accuracy_vs_16bit_v(torch, _native, q, k, v, qa.fp8_attn_func(q, k, v, is_causal=False), False, "e4m3", [0, 3072])
-                    acc["c3"] = accuracy_vs_16bit_v(torch, _native, q, k, v, qa.fp8_attn_func(q, k, v, is_causal=True), True, "e4m3", [0, 1024, 3072])
+                    acc["c2"] = accuracy_of_step(torch, _native, q, k, v, qa.fp8_attn_func(q, k, v, is_causal=False), False, "e4m3", [0, 3072])
+                    acc["c3"] = accuracy_of_step(torch, _native, q, k, v, qa.fp8_attn_func(q, k, v, is_causal=True), True, "e4m3", [0, 1024, 3072])
                 qx, kx, vx = (torch.randn(1, 2, 16384, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
                 with qa.config.patch({"attention.fp8_format": "e5m2", "attention.precision": args.precision}):
-                    acc["c5_shape_B1_H2"] = accuracy_vs_16bit_v(torch, _native, qx, kx, vx, qa.fp8_attn_func(qx, kx, vx, is_causal=True), True, "e5m2", [0, 8192, 15360])
+                    acc["c5_shape_B1_H2"] = accuracy_of_step(torch, _native, qx, kx, vx, qa.fp8_attn_func(qx, kx, vx, is_causal=True), True, "e5m2", [0, 8192, 15360])
                 del qx, kx, vx
-                acc["note"] = ("fp64 SDPA (torch, GPU) of the library's quantised q, k; the 16-bit-V column is the reference's semantics "
-                               "(tk/attention.py:286,318), the quantised-V column uses one scale per head (the fused step scales V per 64-key chunk)")
+                acc["note"] = ("fp64 SDPA (torch, GPU) of the library's quantised q, k; `oracle` = with the V the step really used (block-scaled "
+                               "fp8 V: one power-of-two scale per 64-key chunk, restated in bench.py block_scaled_v) -- the north_star's parity "
+                               "number, bound 2^-6 max(1, |O|max / 2); `16bitV` = with the original 16-bit V, the reference kernel's semantics "
+                               "(tk/attention.py:286,318)")
                 line["accuracy"] = acc
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, q, k, v)

@@ -200,10 +200,15 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
  *                             abs-max launch; with all of them supplied (amax_v is not needed where V is block-scaled: head-wise
  *                             scales, Skv <= 16384, D = 64 / 256 or D = 128 from bf16 inputs) the launch is skipped -- at B4 H32 S4096 D128 that is 0.05 of 0.64 ms.  The
  *                             results are bit-identical to qattn_fp8_quant_attention_forward's -- under QATTN_PRECISION_AUTO when
- *                             ssq_q / ssq_k come along (below); without them and without the abs-max pass the kernel has no
- *                             score-spread estimate, heads with a wide spread start one-term as in the separate calls: the same
- *                             bound, other bits.  A value LARGER than the true
- *                             abs-max is safe (a coarser scale, no clipping) but no longer the reference's scale; a smaller one clips.
+ *                             ssq_q / ssq_k come along (below), except for a head whose estimated score variance sits exactly on
+ *                             the dead-band edge (1.5): the caller's fp32 sums differ from the pass's partial sums in the last
+ *                             bits and may start such a head in the other mode (same bound).  Without the sums: with only ONE of
+ *                             amax_q / amax_k supplied both tensors still go through the abs-max pass for their sums of squares
+ *                             (nothing is saved, the plain call's bits); with BOTH supplied the pass is skipped, the kernel has no
+ *                             score-spread estimate and heads with a wide spread start one-term as in the separate calls: the same
+ *                             bound, other bits.  Preconditions: every value finite; it enters by magnitude (the sign bit is
+ *                             dropped).  A value LARGER than the true abs-max is safe (a coarser scale, no clipping) but no longer
+ *                             the reference's scale; a smaller one clips, a NaN makes that head's scale NaN.
  *   ssq_q / ssq_k             NULL, or fp32 [B,Hq] / [B,Hkv]: sum of x^2 over each head (both or neither).  Only read under
  *                             QATTN_PRECISION_AUTO, where the pre-pass otherwise accumulates them for the score-spread estimate
  *                             that picks a head's starting precision; without them (and without the abs-max pass over q and k)
@@ -252,6 +257,18 @@ int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, 
  * second event), or a negative value when profiling is off.  Off by default; no environment variable changes results. */
 void qattn_profile_attention(int enable);
 float qattn_last_attention_ms(void);
+
+/*
+ * Measurement aid (bench.py `roofline.practical_peak`): a bare v_mfma_f32_32x32x64_f8f6f4 loop -- operands in registers, four
+ * independent accumulators per wave, two waves per SIMD, one 512-thread workgroup per CU -- on the fp8 bytes the caller put into
+ * the first 64 KiB of `scratch` (random e4m3 bytes for a figure comparable with the attention kernel's; constant bytes read
+ * 30-40 % higher because the chip holds a higher clock on them).  The rest of `scratch` (qattn_mfma_probe_bytes() in all) receives
+ * {shader cycles, 100 MHz ticks} of every wave's loop: cycles / ticks x 0.1 = the clock in GHz inside the loop.  *flops_per_launch
+ * = iters x 4 x waves x 2 x 32 x 32 x 64; the caller times the launches (HIP events on `stream`).  No reference counterpart; the
+ * attention path never calls it.
+ */
+size_t qattn_mfma_probe_bytes(void);
+int qattn_mfma_probe(void* scratch, size_t scratch_bytes, int iters, double* flops_per_launch, int* waves, void* stream);
 
 #ifdef __cplusplus
 }

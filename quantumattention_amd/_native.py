@@ -32,7 +32,7 @@ EXPORTS = (
     "qattn_16bit_tensor_bytes", "qattn_pack16", "qattn_attention_forward_16", "qattn_fp8_quant_attention_forward",
     "qattn_attention_workspace_bytes", "qattn_lse_row_stride", "qattn_fp8_quant_attention_workspace_bytes",
     "qattn_profile_attention", "qattn_last_attention_ms", "qattn_vblock_exponent", "qattn_fp8_quant_attention_forward_ex",
-    "qattn_attention_stamp_bytes", "qattn_fp8_quant_attention_forward_stamped",
+    "qattn_attention_stamp_bytes", "qattn_fp8_quant_attention_forward_stamped", "qattn_mfma_probe_bytes", "qattn_mfma_probe",
 )
 
 _lib = None
@@ -48,6 +48,12 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m quantumattention_amd.build` "
             "(hipcc --offload-arch=gfx950). The gfx950 FP8 attention path has no CPU or eager fallback."
         )
+    if os.path.abspath(LIB_PATH) != os.path.join(_HERE, "libqattn_hip.so"):
+        # never silent: a stale variant with the right ABI number would otherwise be timed or shipped unnoticed
+        import warnings
+
+        warnings.warn(f"quantumattention_amd: loading a NON-DEFAULT kernel library {LIB_PATH} (QUANTUM_ATTN_LIBRARY / LIB_PATH "
+                      "override; development aid)", RuntimeWarning, stacklevel=2)
     L = ctypes.CDLL(LIB_PATH)
     vp, i, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     L.qattn_abi_version.restype = i
@@ -94,6 +100,10 @@ def lib() -> ctypes.CDLL:
     L.qattn_attention_stamp_bytes.argtypes = [i, i, i]
     L.qattn_fp8_quant_attention_forward_stamped.restype = i
     L.qattn_fp8_quant_attention_forward_stamped.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp, sz, vp]
+    L.qattn_mfma_probe_bytes.restype = sz
+    L.qattn_mfma_probe_bytes.argtypes = []
+    L.qattn_mfma_probe.restype = i
+    L.qattn_mfma_probe.argtypes = [vp, sz, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), vp]
     if L.qattn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libqattn_hip.so ABI {L.qattn_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = L
@@ -114,6 +124,17 @@ def _scale_mode(scaling: str) -> int:
 def _precision(name) -> int:
     _require(name in PRECISION, f"Unsupported precision: {name!r} (expected one of {sorted(PRECISION)})")
     return PRECISION[name]
+
+
+def _numerics(name) -> int:
+    _require(name in NUMERICS, f"Unsupported quant_numerics: {name!r} (expected one of {sorted(NUMERICS)})")
+    return NUMERICS[name]
+
+
+def fp8_dtype_of(name) -> torch.dtype:
+    """config.attention.fp8_format / the ops' fp8_format argument -> torch dtype; anything else is a ValueError, not a KeyError."""
+    _require(name in FP8_DTYPE, f"Unsupported fp8_format: {name!r} (expected one of {sorted(FP8_DTYPE)})")
+    return FP8_DTYPE[name]
 
 
 def _check_qkv(q, k, v):
@@ -179,7 +200,7 @@ def quant_fp8(x: torch.Tensor, *, scaling: str = "head-wise", fp8_dtype=torch.fl
         ws_bytes = L.qattn_quant_workspace_bytes(B, H, S, D, mode)
         ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x.device)
         rc = L.qattn_quant_fp8(x.data_ptr(), fmt_of(x.dtype), out.data_ptr(), scale.data_ptr(), B, H, S, D,
-                               fmt_of(fp8_dtype), mode, NUMERICS[numerics], layout, ws.data_ptr(), ws_bytes,
+                               fmt_of(fp8_dtype), mode, _numerics(numerics), layout, ws.data_ptr(), ws_bytes,
                                _stream(x))
     _check(rc, "qattn_quant_fp8")
     return out, scale
@@ -204,7 +225,7 @@ def quant_qkv_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scaling:
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         rc = L.qattn_quant_qkv_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), q8.data_ptr(),
                                    kf.data_ptr(), vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(),
-                                   B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode, NUMERICS[numerics],
+                                   B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode, _numerics(numerics),
                                    ws.data_ptr(), ws_bytes, _stream(q))
     _check(rc, "qattn_quant_qkv_fp8")
     return q8, kf, vf, sq, sk, sv
@@ -333,7 +354,7 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
             q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
             vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), _ptr(amax_q), _ptr(amax_k), _ptr(amax_v), _ptr(ssq_q),
             _ptr(ssq_k), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
-            NUMERICS[numerics], int(is_causal), float(sm_scale), _precision(precision), ws.data_ptr(), ws_bytes, _stream(q))
+            _numerics(numerics), int(is_causal), float(sm_scale), _precision(precision), ws.data_ptr(), ws_bytes, _stream(q))
     _check(rc, "qattn_fp8_quant_attention_forward_ex")
     return out
 
@@ -369,3 +390,45 @@ def measure_attention_clock(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *
     s = s[s[:, 1] > 0]
     clock = (s[:, 0] / s[:, 1] * 0.1)
     return float(clock.median()), float(s[:, 0].median()), out
+
+
+def measure_mfma_peak(device=None, *, seconds: float = 0.3, iters: int = 20000, constant: bool = False):
+    """Measurement aid (qattn_mfma_probe): TFLOP/s and in-kernel clock (GHz) of a bare v_mfma_f32_32x32x64_f8f6f4 loop on random
+    e4m3 operand bytes (|x| in [2^-2, 2^2), random sign and mantissa -- the regime of quantised N(0,1) data), two waves per SIMD on
+    every CU, launched back to back for `seconds`; the figures are those of the last third of the run (settled clocks)."""
+    L = lib()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        nbytes = L.qattn_mfma_probe_bytes()
+        scratch = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        n_op = 2048 * 32
+        if constant:
+            scratch[:n_op] = 0x38
+        else:
+            expo = torch.randint(0x28, 0x48, (n_op,), generator=g, device=dev, dtype=torch.int32)
+            sign = torch.randint(0, 2, (n_op,), generator=g, device=dev, dtype=torch.int32) << 7
+            scratch[:n_op] = (expo | sign).to(torch.uint8)
+        fl, nw = ctypes.c_double(0.0), ctypes.c_int(0)
+        call = lambda: _check(L.qattn_mfma_probe(scratch.data_ptr(), nbytes, iters, ctypes.byref(fl), ctypes.byref(nw), _stream(scratch)),
+                              "qattn_mfma_probe")
+        call()
+        torch.cuda.synchronize(dev)
+        import time as _time
+
+        t_end, laps = _time.perf_counter() + seconds, []
+        while _time.perf_counter() < t_end or len(laps) < 3:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call()
+            e1.record()
+            laps.append((e0, e1))
+        torch.cuda.synchronize(dev)
+        ms = sorted(a.elapsed_time(b) for a, b in laps[len(laps) * 2 // 3:])
+        med = ms[len(ms) // 2]
+        st = scratch[n_op:n_op + 16 * nw.value].view(torch.int64).view(-1, 2).double().cpu()
+        st = st[st[:, 1] > 0]
+        clock = float((st[:, 0] / st[:, 1] * 0.1).median())
+    return {"TFLOPs": fl.value / (med * 1e-3) / 1e12, "in_kernel_clock_ghz": clock, "ms_per_launch": med, "launches": len(laps),
+            "waves": nw.value, "operands": "constant 1.0" if constant else "random e4m3, |x| in [2^-2, 2^2)"}

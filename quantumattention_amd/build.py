@@ -4,6 +4,7 @@ The reference JIT-compiles its CUDA kernel with nvcc on first call (src/quantum_
 here the library is built in-tree once (`python -m quantumattention_amd.build` or `__graft_entry__.build()`),
 and the built `.so` travels with the source tree.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -17,7 +18,7 @@ BUILD = os.path.join(HERE, "_build")
 # directory of its own that neither git nor gpurun ships (.gitignore, .gpurunignore); the objects of the shipped library do not
 BUILD_TEMPS = os.path.join(HERE, "_build_temps")
 LIB = os.path.join(HERE, "libqattn_hip.so")
-SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip"]
+SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip"]
 # (source, extra flags, object name): the two big kernel files are compiled once per operand format / head dimension so that
 # the build runs in parallel (the longest single translation unit sets the wall time)
 # (a unit with a define is compiled through a two-line wrapper file named after the unit, so that -save-temps leaves one .s
@@ -31,6 +32,7 @@ UNITS = [
     ("qattn_attn16.hip", [], "qattn_attn16"),
     ("qattn_quant.hip", [], "qattn_quant"),
     ("qattn_api.hip", [], "qattn_api"),
+    ("qattn_probe.hip", [], "qattn_probe"),
 ]
 # `--dev` builds libqattn_hip_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
 # QATTN_* environment switches.  The product library contains none of them.
@@ -59,7 +61,15 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
     BUILD_TEMPS instead (same flags, same code; the library is left alone) and return that directory.
     variant / extra_defines (development): a library of its own, tools/bin/libqattn_<variant>.so, compiled with the given -D macros
     (kernel tuning knobs) for A/B runs with tools/ab.py or tools/kstats.sh."""
-    build_dir = BUILD_TEMPS if save_temps else BUILD + ("_dev" if dev else "") + (f"_var_{variant}" if variant else "")
+    extra_defines = sorted(extra_defines)
+    if save_temps and (variant or extra_defines or dev):
+        # BUILD_TEMPS is what the resource / hazard tests read: only the product configuration may write there
+        raise ValueError("save_temps is for the product configuration only (no variant, no -D macros, no --dev)")
+    if extra_defines and not variant:
+        raise ValueError("-D macros need --variant=<name>: the product and dev libraries are built without tuning macros")
+    # the macros are part of the object directory's name: another set of -D values never reuses stale objects
+    tag = ("_" + hashlib.sha1(" ".join(extra_defines).encode()).hexdigest()[:8]) if extra_defines else ""
+    build_dir = BUILD_TEMPS if save_temps else BUILD + ("_dev" if dev else "") + (f"_var_{variant}{tag}" if variant else "")
     lib = LIB.replace(".so", "_dev.so") if dev else LIB
     if variant:
         lib = os.path.join(os.path.dirname(HERE), "tools", "bin", f"libqattn_{variant}.so")

@@ -30,6 +30,11 @@ class attention:
     #   "accurate" two-term P everywhere (about bf16-P accuracy, ~1.5x the matrix work)
     precision = os.getenv("QUANTUM_ATTN_PRECISION", "auto")
 
+    # torch.compile: trace the per-head abs-max (and sums of squares) of query / key / value into the caller's graph as aten reductions, so
+    # that Inductor fuses them into the kernel that produced the tensors and the quant pre-pass skips its abs-max launch -- what the
+    # reference gets from inlining its quantiser into the compiled region (nn.py:410-418, 484-501).  Eager calls are not affected.
+    inline_abs_max_under_compile = os.getenv("QUANTUM_ATTN_INLINE_ABS_MAX", "1") == "1"
+
     # 16-bit sibling path (attn_func): False = exact v_exp_f32 softmax (default); True = the linear-mantissa 2^x
     # approximation for rows that see >= 1024 keys (+9 % speed, 1.8 % rms error in P: fine for flat rows only)
     fast_exp16 = os.getenv("QUANTUM_ATTN_FAST_EXP16") == "1"

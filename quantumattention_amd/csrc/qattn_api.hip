@@ -403,6 +403,8 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     if (!workspace || workspace_bytes < qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)) return QATTN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode, is_causal);
+    // the measurement entry exists for one instantiation only: refuse before the pre-pass has written anything
+    if (stamps && !(fuse_q && fp8_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
     // (Tried and dropped, profiles/r02_overlap.md: running the HBM-bound pre-pass of batch group g+1 on a second stream beside
     // the attention of group g.  The 512-thread attention workgroups leave 32-48 VGPRs per SIMD, the pre-pass waves displace
     // them instead of sharing the CU, and the chip is power-limited on the attention kernel: the step got 19-31 % SLOWER.)
@@ -411,7 +413,10 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     // the score-spread estimate needs both heads' sums of squares: from the abs-max pass when it reads q AND k, else from the caller
     const bool auto_head = precision == QATTN_PRECISION_AUTO && scale_mode == QATTN_SCALE_HEAD;
     const bool ext_moments = auto_head && ssq_q != nullptr;
-    const bool moments = auto_head && !ext_moments && !amax_q && !amax_k;
+    // (a caller that hands over only ONE of amax_q / amax_k without the sums keeps the estimate: both tensors then still go
+    // through the abs-max pass for their sums of squares -- the supplied abs-max is used for the scale, nothing is saved, and the
+    // call produces the plain call's bits; with BOTH supplied and no sums the pass is skipped and wide heads start one-term)
+    const bool moments = auto_head && !ext_moments && !(amax_q && amax_k);
     // block-scaled V with head-wise scales wherever the kernel's PV products take the chunk's scale byte -- the hand-scheduled
     // D = 128 kernel in its fused-Q instantiation, the templated kernel (D = 64 / 256) -- and a head has at most kMomentSplits
     // chunks: V then needs no abs-max pass

@@ -837,7 +837,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
         static_assert(kVxWords <= NW * 64, "one V scale word per thread");
         if (!(p.vexp && tid < p.nchunks)) vxw = 127u;
         if (tid < kVxWords) vx[tid] = (unsigned)vscale_word(vxw);
-        const unsigned am = max(max(a0, a1), max(a2, a3));
+        const unsigned am = max(max(a0, a1), max(a2, a3)) & 0x7fffffffu;   // (a caller-supplied abs-max enters by magnitude)
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
         scale_q16 = make_scale(__uint_as_float(wave_allmax_u32(am)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
@@ -913,7 +913,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     float c, scale_q16 = 1.0f;
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane) & 0x7fffffffu), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         c = p.sm_log2e * scale_q16 * p.sk[kv_head];
         for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (unsigned)vscale_word((p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u);
         __syncthreads();

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
     float scale = 1.0f;
     if (!token && !(layout == QATTN_LAYOUT_VFRAG && jobs.vexp != nullptr)) {
-        const unsigned amax_bits = jb.amax_ext ? jb.amax_ext[g] : max_partials(jb.amax_part + (long)g * kMomentSplits, jobs.nsplit, tid & 63);
+        const unsigned amax_bits = jb.amax_ext ? (jb.amax_ext[g] & 0x7fffffffu) : max_partials(jb.amax_part + (long)g * kMomentSplits, jobs.nsplit, tid & 63);
         scale = make_scale(__uint_as_float(amax_bits), inv_qmax, numerics, IN_FMT);
         if (tile_first - kQuantTilesPerBlock < 0 && tid == 0) jb.scale[g] = scale;   // (the block that holds tile 0)
     }
@@ -791,7 +791,7 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
     // scales; V always has one scale per head, or none of its own when block-scaled)
     int npass = 0;
     for (int t = 0; t < 3; t++)
-        if (!ext[t] && (t == 2 ? !vblock : !tok)) jobs.zmap[npass++] = t;
+        if ((!ext[t] || (moments && t < 2)) && (t == 2 ? !vblock : !tok)) jobs.zmap[npass++] = t;   // (moments: q and k are read for their sums of squares whoever supplies the abs-max)
     for (int t = npass; t < 3; t++) jobs.zmap[t] = 0;
     // (Tried and dropped: one tensor at a time -- amax then quantise, hoping the re-read hits the 256 MiB Infinity Cache --
     // was 13 % slower than the two fused launches; a one-pass register-resident variant with a cross-workgroup amax

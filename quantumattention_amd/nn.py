@@ -228,7 +228,10 @@ def can_use_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causa
 
 
 def _fp8_dtype() -> torch.dtype:
-    return torch.float8_e5m2 if _cfg("fp8_format") == "e5m2" else torch.float8_e4m3fn
+    name = _cfg("fp8_format")
+    if name not in ("e4m3", "e5m2"):
+        raise ValueError(f"Unsupported config.attention.fp8_format: {name!r} (expected 'e4m3' or 'e5m2')")
+    return torch.float8_e5m2 if name == "e5m2" else torch.float8_e4m3fn
 
 
 def _dynamically_quantize_fp8(t: torch.Tensor, *, reduction_dim=-1, fp8_dtype=None):
@@ -307,6 +310,17 @@ def attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False,
                               scale=scale)
 
 
+def _head_abs_max(t: Tensor) -> Tensor:
+    """fp32 [B,H] max |x| over each head of a 16-bit [B,H,S,D] tensor (exact: the fp32 value of the largest 16-bit magnitude)."""
+    return t.abs().amax(dim=(-2, -1)).to(torch.float32)
+
+
+def _head_sum_sq(t: Tensor) -> Tensor:
+    """fp32 [B,H] sum of x^2 over each head."""
+    f = t.to(torch.float32)
+    return (f * f).sum(dim=(-2, -1))
+
+
 def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None,
                            scale_q=None, scale_k=None, scaling_method=None, amax_q=None, amax_k=None, ssq_q=None,
                            ssq_k=None) -> Tensor:
@@ -324,9 +338,21 @@ def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_
             raise ValueError("amax_q / amax_k / ssq_q / ssq_k are per-head figures: head-wise scaling only")
         if (ssq_q is None) != (ssq_k is None):
             raise ValueError("ssq_q and ssq_k must be both provided or both not provided")
+        amax_v = None
+        if (torch.compiler.is_dynamo_compiling() and scaling_method == "head-wise" and not any(given)
+                and _cfg("inline_abs_max_under_compile")):
+            # The reference's quantiser is traced INTO the caller's graph (nn.py:410-418, 484-501) and Inductor fuses its abs-max
+            # reduction with whatever produced query / key.  Same effect here: the per-head abs-max (and, for precision="auto", the
+            # sums of squares of its score-spread estimate) are emitted as aten reductions in the caller's graph -- Inductor fuses
+            # them into the producer's kernel -- and handed to the op, whose abs-max launch then has nothing left to read
+            # (qattn_fp8_quant_attention_forward_ex).  abs().amax() of a 16-bit tensor is exact, so the scales and the output are
+            # those of the eager call bit for bit (sums of squares: include/qattn.h on the dead-band edge).
+            amax_q, amax_k, amax_v = (_head_abs_max(t) for t in (query, key, value))
+            if _cfg("precision") == "auto":
+                ssq_q, ssq_k = _head_sum_sq(query), _head_sum_sq(key)
         return ops.fp8_quant_attention_forward(
             query, key, value, is_causal, scaling_method, _cfg("fp8_format"),
-            _cfg("quant_numerics"), _cfg("precision"), amax_q, amax_k, ssq_q, ssq_k, scale=scale)
+            _cfg("quant_numerics"), _cfg("precision"), amax_q, amax_k, ssq_q, ssq_k, amax_v, scale=scale)
     if any(t is not None for t in (amax_q, amax_k, ssq_q, ssq_k)):
         raise ValueError("amax_q / amax_k describe 16-bit query / key; fp8 query / key come with scale_q / scale_k")
     return ops.fp8_attention_forward(
@@ -356,7 +382,10 @@ def fp8_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=Fa
     amax_q / amax_k (build extension, keyword-only): fp32 [B,H] per-head max |x| of 16-bit query / key from their producer --
     the quant pre-pass then skips its abs-max launch (the reference's Inductor fusion, nn.py:410-418).
     ssq_q / ssq_k (both or neither): fp32 [B,H] per-head sums of squares; with precision="auto" they stand in for the moments the
-    skipped pass would have collected (without them heads with a wide score spread start one-term: same bound, other bits)."""
+    skipped pass would have collected (without them heads with a wide score spread start one-term: same bound, other bits).
+    Preconditions on amax_*: finite, >= the tensor's true abs-max (a smaller value clips; the sign is ignored; a NaN makes the head's
+    scale NaN).  With only one of amax_q / amax_k and no ssq_* under precision="auto" nothing is saved (both tensors are still read for
+    their sums of squares) and the result is the plain call's, bit for bit."""
     supported, reason = can_use_attention(
         query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
         scaling_method=scaling_method, scale_q=scale_q, scale_k=scale_k)

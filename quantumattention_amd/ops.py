@@ -124,6 +124,7 @@ def fp8_quant_attention_forward(
     amax_k: Optional[torch.Tensor] = None,
     ssq_q: Optional[torch.Tensor] = None,
     ssq_k: Optional[torch.Tensor] = None,
+    amax_v: Optional[torch.Tensor] = None,
     *,
     scale: Optional[float] = None,
 ) -> torch.Tensor:
@@ -132,16 +133,18 @@ def fp8_quant_attention_forward(
     reference through Inductor, without the intermediate row-major K copy.  amax_q / amax_k (fp32 [B,H], head-wise only):
     per-head max |x| of query / key from the kernel that produced them; the abs-max launch then has nothing to read --
     the hand-off the reference gets from Inductor fusing the quantiser into the producer.  ssq_q / ssq_k (fp32 [B,H], both or
-    neither): per-head sums of squares, which keep precision="auto" its score-spread estimate when the abs-max pass is skipped."""
+    neither): per-head sums of squares, which keep precision="auto" its score-spread estimate when the abs-max pass is skipped.
+    amax_v (fp32 [B,Hkv]): the same for value, read only where V has one scale per head (fp16 inputs at D = 128; elsewhere the fused
+    step scales V per 64-key chunk inside the quantise pass and needs no abs-max of it)."""
     return _native.fp8_quant_attention_forward(
-        query, key, value, is_causal=is_causal, scaling=scaling_method, fp8_dtype=_native.FP8_DTYPE[fp8_format],
+        query, key, value, is_causal=is_causal, scaling=scaling_method, fp8_dtype=_native.fp8_dtype_of(fp8_format),
         numerics=numerics, sm_scale=0.0 if scale is None else float(scale), precision=precision, amax_q=amax_q, amax_k=amax_k,
-        ssq_q=ssq_q, ssq_k=ssq_k)
+        amax_v=amax_v, ssq_q=ssq_q, ssq_k=ssq_k)
 
 
 @_register_fake("quantumattention_amd::fp8_quant_attention_forward")
 def _(query, key, value, is_causal=False, scaling_method="head-wise", fp8_format="e4m3", numerics="compiled",
-      precision="auto", amax_q=None, amax_k=None, ssq_q=None, ssq_k=None, *, scale=None):
+      precision="auto", amax_q=None, amax_k=None, ssq_q=None, ssq_k=None, amax_v=None, *, scale=None):
     return _out_like(query, value)
 
 
@@ -150,12 +153,12 @@ def dynamically_quantize_fp8_op(t: torch.Tensor, token_wise: bool, fp8_format: s
                                 numerics: str = "compiled") -> tuple[torch.Tensor, torch.Tensor]:
     """HIP quant pre-pass for a 4-D [B,H,S,D] tensor (nn.py:14-19): head-wise (dims 2,3) or token-wise (dim 3)."""
     return _native.quant_fp8(t, scaling="token-wise" if token_wise else "head-wise",
-                             fp8_dtype=_native.FP8_DTYPE[fp8_format], layout=_native.LAYOUT_ROWMAJOR,
+                             fp8_dtype=_native.fp8_dtype_of(fp8_format), layout=_native.LAYOUT_ROWMAJOR,
                              numerics=numerics)
 
 
 @_register_fake("quantumattention_amd::dynamically_quantize_fp8")
 def _(t, token_wise, fp8_format="e4m3", numerics="compiled"):
-    q = torch.empty(t.shape, dtype=_native.FP8_DTYPE[fp8_format], device=t.device)
+    q = torch.empty(t.shape, dtype=_native.fp8_dtype_of(fp8_format), device=t.device)
     s = torch.empty(t.shape[:3] if token_wise else t.shape[:2], dtype=torch.float32, device=t.device)
     return q, s

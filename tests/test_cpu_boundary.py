@@ -226,3 +226,63 @@ def test_vblock_exponent_matches_the_oracle_restatement():
             if np.isfinite(a) and a >= 1.1754944e-38:   # the smallest power of two that brings the chunk inside the format's range
                 fmax = 448.0 if fmt == oracle.FMT_E4M3 else 57344.0
                 assert a / 2.0 ** got <= fmax and (got == -126 or a / 2.0 ** (got - 1) > fmax), (name, vals[i], got)
+
+
+def test_config_strings_are_validated_with_readable_errors():
+    """VERDICT r3 hygiene: unknown `numerics` / `fp8_format` / `precision` strings raise ValueError naming the choices (they used to
+    surface as a bare KeyError, and nn._fp8_dtype silently mapped anything that is not "e5m2" to e4m3)."""
+    import quantumattention_amd as qa
+    from quantumattention_amd import _native, nn
+
+    for fn, bad in ((_native._numerics, "jit"), (_native.fp8_dtype_of, "e3m4"), (_native._precision, "exact")):
+        with pytest.raises(ValueError, match="expected"):
+            fn(bad)
+    assert _native._numerics("eager") == 1 and _native.fp8_dtype_of("e5m2") is torch.float8_e5m2
+    with qa.config.patch({"attention.fp8_format": "fp8"}):
+        with pytest.raises(ValueError, match="fp8_format"):
+            nn._fp8_dtype()
+    with qa.config.patch({"attention.fp8_format": "e5m2"}):
+        assert nn._fp8_dtype() is torch.float8_e5m2
+
+
+def test_variant_builds_cannot_touch_the_product_temps():
+    """-D tuning macros are part of a variant's object directory, and -save-temps output (what the resource and
+    hazard tests read) can only come from the product configuration."""
+    from quantumattention_amd import build
+
+    with pytest.raises(ValueError):
+        build.build(save_temps=True, variant="x")
+    with pytest.raises(ValueError):
+        build.build(save_temps=True, extra_defines=["QATTN_QUANT_TPB=2"])
+    with pytest.raises(ValueError):
+        build.build(extra_defines=["QATTN_QUANT_TPB=2"])
+
+
+def test_compiled_region_carries_the_abs_max_reductions():
+    """SURVEY 8f-4 / VERDICT r3 Missing-2: under torch.compile the reference's quantiser is part of the caller's graph (nn.py:410-418,
+    484-501), so Inductor fuses its abs-max with the producer of q / k.  Here the per-head abs-max and sums of squares are traced as
+    aten reductions and handed to the fused op (whose abs-max launch is then skipped).  Traced on CPU tensors (fake impls only)."""
+    import torch._dynamo
+
+    def f(x, k, v):
+        q = x * 1.5                                   # a producer of q inside the compiled region
+        return qa.fp8_attn_func(q, k, v, is_causal=True)
+
+    x, k, v = (torch.randn(1, 2, 128, 128, dtype=torch.bfloat16) for _ in range(3))
+    for inline, precision in ((True, "auto"), (True, "fast"), (False, "auto")):
+        torch._dynamo.reset()
+        with qa.config.patch({"attention.skip_supported_check": True, "attention.inline_abs_max_under_compile": inline,
+                              "attention.precision": precision}):
+            gm = torch._dynamo.export(f)(x, k, v).graph_module
+        nodes = list(gm.graph.nodes)
+        op = [n for n in nodes if n.op == "call_function" and "fp8_quant_attention_forward" in str(n.target)]
+        assert len(op) == 1
+        names = "query key value is_causal scaling_method fp8_format numerics precision amax_q amax_k ssq_q ssq_k amax_v".split()
+        args = dict(zip(names, op[0].args), **op[0].kwargs)
+        n_amax = sum(1 for n in nodes if n.op == "call_method" and n.target == "amax")
+        if inline:
+            assert n_amax == 3 and all(args.get(a) is not None for a in ("amax_q", "amax_k", "amax_v"))
+            assert (args.get("ssq_q") is not None) == (precision == "auto") == (args.get("ssq_k") is not None)
+        else:
+            assert n_amax == 0 and all(args.get(a) is None for a in ("amax_q", "amax_k", "amax_v", "ssq_q", "ssq_k"))
+    torch._dynamo.reset()

@@ -305,7 +305,8 @@ def test_hip_graph_capture_of_the_whole_step(B, H, S):
     """The C ABI promises "no host synchronisation, no allocation, graph-capture safe" (include/qattn.h): capture
     quant pre-pass + attention (and the 16-bit path) in a HIP graph, replay it on new input data, compare bit-exactly
     with the eager launches.  The larger causal shape (512 blocks > CUs) runs the persistent launch whose block hand-out
-    counters are zeroed by a memset node of the same capture."""
+    counters are cleared by a KERNEL of the same capture (the quantise pass in the fused step, zero_words_kernel otherwise: as a
+    memset node the 32-byte fill faulted on the second replay)."""
     torch.manual_seed(11)
     D = 128
     q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
@@ -403,6 +404,47 @@ def test_c_abi_error_codes_instead_of_exceptions():
         assert len(L.qattn_strerror(code)) > 0
 
 
+@pytest.mark.parametrize("precision", ["auto", "fast"])
+def test_compiled_producer_fuses_the_abs_max_and_skips_the_pre_pass_launch(precision):
+    """SURVEY 8f-4 / VERDICT r3 Missing-2 (nn.py:410-418, 484-501): q = producer(x) inside a torch.compile region.  The per-head
+    abs-max (and the sums of squares for precision="auto") are traced as aten reductions, Inductor fuses them with the producer, and
+    the op receives them: the kernel trace of the compiled call holds NO amax_multi_kernel, and the output is the eager call's bit for
+    bit (abs().amax() of a 16-bit tensor is exact)."""
+    torch.manual_seed(17)
+    B, H, S, D = 2, 8, 2048, 128
+
+    def f(x, wk, v):
+        q = (x * 1.25).to(torch.bfloat16)           # stand-ins for a projection / RoPE epilogue
+        k = (wk + 0.5 * wk.roll(1, -1)).to(torch.bfloat16)
+        return qa.fp8_attn_func(q, k, v, is_causal=True)
+
+    x, wk, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    with qa.config.patch({"attention.precision": precision}):
+        want = f(x, wk, v)
+        try:
+            cf = torch.compile(f, backend="inductor", fullgraph=True)
+            got = cf(x, wk, v)
+        except Exception as exc:  # no working Triton / C++ toolchain for Inductor on this box: nothing of ours to test
+            if "quantumattention_amd" in str(exc):
+                raise
+            pytest.skip(f"inductor backend unavailable here: {type(exc).__name__}: {str(exc)[:200]}")
+        assert torch.equal(got, want)
+        from torch.profiler import ProfilerActivity, profile
+
+        def kernels(fn):
+            with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+                fn(x, wk, v)
+                torch.cuda.synchronize()
+            return [e.key for e in prof.key_averages() if e.device_type is not None and "DeviceType.CUDA" in str(e.device_type)]
+
+        eager_k, comp_k = kernels(f), kernels(cf)
+    if not any("attn_fwd_kernel" in n for n in eager_k):
+        pytest.skip("the profiler reports no device kernels on this box")
+    assert any("amax_multi_kernel" in n for n in eager_k), eager_k
+    assert any("attn_fwd_kernel" in n for n in comp_k) and any("quant_multi_kernel" in n for n in comp_k), comp_k
+    assert not any("amax_multi_kernel" in n for n in comp_k), comp_k
+
+
 @pytest.mark.parametrize("causal,B,H,S", [(True, 4, 8, 4096), (False, 8, 32, 6144)])
 def test_null_workspace_runs_the_static_launch_with_the_same_bits(causal, B, H, S):
     """include/qattn.h: the attention workspace may be NULL for FAST / ACCURATE; a causal launch then uses one workgroup per query
@@ -470,6 +512,66 @@ def test_producer_supplied_abs_max_is_bit_identical(D, causal, fp8, dtype):
         _native.fp8_quant_attention_forward(q, k, v, **kw, ssq_q=ssq(q))                           # both or neither
     with pytest.raises(ValueError):
         qa.nn.fp8_attention(q, k, v, is_causal=causal, scaling_method="token-wise", amax_q=aq)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("qmul", [1.0, 1.3, 2.0])
+def test_producer_hand_off_on_one_term_sweeps(causal, qmul):
+    """the hand-off test above uses S = 1000 < kTwoTermKeys, where every block starts two-term.  Here S = 2048 .. 4096
+    (one-term sweeps: the caller's abs-max word read by q_amax_part with amax_n = 1, the caller's sums with ssq_n = 1 through
+    sum_partials_pair) and q scaled so that some heads leave the dead band of the variance estimate (1.5) and start two-term:
+      * abs-max AND sums supplied: the plain call's bits (heads exactly on the dead-band edge excepted -- none here: the estimates
+        of these inputs are 1.0, 1.7 and 4.0 per head, far from 1.5);
+      * only ONE abs-max, no sums: both tensors still take the abs-max pass for their sums -> the plain call's bits;
+      * both abs-max, no sums: no score-spread estimate, wide heads start one-term: the documented bound, not the bits."""
+    torch.manual_seed(33)
+    B, H, S, D = 1, 4, 2048 if causal else 2560, 128
+    q = (torch.randn(B, H, S, D, device="cuda") * qmul).to(torch.bfloat16)
+    k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    q[:, 0] = (q[:, 0].float() / qmul).to(torch.bfloat16)   # head 0 stays flat: both regimes in one launch
+    kw = dict(is_causal=causal, precision="auto")
+    base = _native.fp8_quant_attention_forward(q, k, v, **kw)
+    amax = lambda t: t.abs().amax(dim=(2, 3)).float()
+    ssq = lambda t: (t.float() ** 2).sum(dim=(2, 3))
+    aq, ak = amax(q), amax(k)
+    full = _native.fp8_quant_attention_forward(q, k, v, **kw, amax_q=aq, amax_k=ak, ssq_q=ssq(q), ssq_k=ssq(k))
+    assert torch.equal(full, base)
+    assert torch.equal(_native.fp8_quant_attention_forward(q, k, v, **kw, amax_q=aq), base)
+    assert torch.equal(_native.fp8_quant_attention_forward(q, k, v, **kw, amax_k=ak), base)
+    bare = _native.fp8_quant_attention_forward(q, k, v, **kw, amax_q=aq, amax_k=ak)
+    # the error bound holds either way (oracle: fp64 SDPA of the quantised q, k and the block-scaled V the step used)
+    q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal, v_block=fused_step_uses_block_v(D, "head", q.dtype, S))
+    for name, got in (("with sums", full), ("abs-max only", bare)):
+        mx, rmse = err_stats(out_to_f32(got), ref)
+        assert mx < TOL, (name, mx, rmse)
+    if qmul >= 2.0:
+        assert torch.equal(bare[:, 0], base[:, 0])   # the flat head takes the same decisions with and without the estimate
+
+
+def test_stamped_entry_refuses_unsupported_shapes_before_the_pre_pass():
+    """qattn_fp8_quant_attention_forward_stamped on D = 64 returned QATTN_ERR_UNSUPPORTED_FMT only after the pre-pass had
+    written q8 / k8 / v8 / scales.  The check now sits in front of the first launch: nothing is written."""
+    import ctypes
+
+    torch.manual_seed(2)
+    B, H, S, D = 1, 2, 512, 64
+    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    L = _native.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    sentinel = 0x5A
+    bufs = [torch.full((B * H * S * D + 4096,), sentinel, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    scales = [torch.full((B, H), -7.0, dtype=torch.float32, device="cuda") for _ in range(3)]
+    out = torch.empty_like(q)
+    ws = torch.zeros(L.qattn_fp8_quant_attention_workspace_bytes(B, H, H, S), dtype=torch.uint8, device="cuda")
+    stamps = torch.zeros(max(L.qattn_attention_stamp_bytes(B, H, S), 16), dtype=torch.uint8, device="cuda")
+    rc = L.qattn_fp8_quant_attention_forward_stamped(P(q), P(k), P(v), 2, P(out), P(bufs[0]), P(bufs[1]), P(bufs[2]), P(scales[0]), P(scales[1]),
+                                                     P(scales[2]), B, H, H, S, S, D, 0, 0, 0, 0, ctypes.c_float(0.0), 0, P(ws), ctypes.c_size_t(ws.numel()),
+                                                     P(stamps), ctypes.c_size_t(stamps.numel()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == -3, rc   # QATTN_ERR_UNSUPPORTED_FMT
+    assert all(bool((b == sentinel).all()) for b in bufs) and all(bool((s_ == -7.0).all()) for s_ in scales)
 
 
 def test_stamped_measurement_entry_reports_a_clock_and_the_same_output():
