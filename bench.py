@@ -211,7 +211,7 @@ def accuracy_of_step(torch, _native, q, k, v, out, causal, fp8, rows, head=0):
     return worst
 
 
-V16_EARLY_ROWS = False   # the early-row pass attends the original 16-bit V (set when the library does)
+V16_EARLY_ROWS = True   # the fused step attends the original 16-bit V in the query blocks that see < 1024 keys (csrc/qattn_pv16.h)
 
 
 def kernel_label(D, fp8, causal, fused_q):

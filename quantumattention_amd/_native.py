@@ -250,15 +250,22 @@ def fp8_attention_forward(q8: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.
                           sm_scale: float = 0.0, return_lse: bool = False, precision: str = "auto",
                           lse_layout: int = LSE_NATURAL):
     """q8: row-major fp8 [B,Hq,Sq,D]; k_frag / v_frag: fragment-layout buffers for [B,Hkv,Skv,D].
+    v_frag may instead be the ORIGINAL 16-bit value tensor, row-major bf16 / fp16 [B,Hkv,Skv,D] (scale_v = None): the call then runs
+    the reference kernel's own P.V numerics -- 16-bit P on the un-quantised V (tk/attention.py:72,286,318) -- for every row (D = 128).
     return_lse: also the log-sum-exp rows; LSE_REFERENCE gives the reference-defined strided view (include/qattn.h)."""
     _require(q8.is_cuda and q8.dim() == 4, "fp8_attention_forward needs a 4-D device query")
     q8 = q8.contiguous()
     B, Hq, Sq, D = q8.shape
     L = lib()
     mode = _scale_mode(scaling)
+    v_is_16 = v_frag.dtype in (torch.bfloat16, torch.float16)
+    if v_is_16:
+        _require(tuple(v_frag.shape) == (B, Hkv, Skv, D) and scale_v is None and out_dtype == v_frag.dtype,
+                 f"a 16-bit value tensor must be [B,Hkv,Skv,D] = {(B, Hkv, Skv, D)} with scale_v=None and out_dtype = its dtype")
+        v_frag = v_frag.contiguous()
     _check_scales(scale_q, scale_k, scale_v, mode, B, Hq, Hkv, Sq, Skv, q8.device)
     _require(k_frag.numel() * k_frag.element_size() >= L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, Hkv, Skv, D)
-             and v_frag.numel() * v_frag.element_size() >= L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D),
+             and (v_is_16 or v_frag.numel() * v_frag.element_size() >= L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D)),
              "k_frag / v_frag are smaller than the fragment layouts of [B,Hkv,Skv,D]")
     with torch.cuda.device(q8.device):
         out = torch.empty((B, Hq, Sq, D), dtype=out_dtype, device=q8.device)
@@ -272,7 +279,7 @@ def fp8_attention_forward(q8: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.
             q8.data_ptr(), k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
             scale_q.contiguous().data_ptr(), scale_k.contiguous().data_ptr(),
             _ptr(scale_v.contiguous() if scale_v is not None else None),
-            B, Hq, Hkv, Sq, Skv, D, fmt_of(q8.dtype), fmt_of(q8.dtype), fmt_of(out_dtype), mode, int(is_causal),
+            B, Hq, Hkv, Sq, Skv, D, fmt_of(q8.dtype), fmt_of(v_frag.dtype if v_is_16 else q8.dtype), fmt_of(out_dtype), mode, int(is_causal),
             float(sm_scale), _precision(precision), lse_layout, ws.data_ptr(), ws_bytes, _stream(q8))
     _check(rc, "qattn_fp8_attention_forward")
     if return_lse:

@@ -18,7 +18,7 @@ BUILD = os.path.join(HERE, "_build")
 # directory of its own that neither git nor gpurun ships (.gitignore, .gpurunignore); the objects of the shipped library do not
 BUILD_TEMPS = os.path.join(HERE, "_build_temps")
 LIB = os.path.join(HERE, "libqattn_hip.so")
-SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip"]
+SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip", "qattn_attn_pv16.hip"]
 # (source, extra flags, object name): the two big kernel files are compiled once per operand format / head dimension so that
 # the build runs in parallel (the longest single translation unit sets the wall time)
 # (a unit with a define is compiled through a two-line wrapper file named after the unit, so that -save-temps leaves one .s
@@ -33,6 +33,7 @@ UNITS = [
     ("qattn_quant.hip", [], "qattn_quant"),
     ("qattn_api.hip", [], "qattn_api"),
     ("qattn_probe.hip", [], "qattn_probe"),
+    ("qattn_attn_pv16.hip", [], "qattn_attn_pv16"),
 ]
 # `--dev` builds libqattn_hip_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
 # QATTN_* environment switches.  The product library contains none of them.

@@ -30,6 +30,13 @@ class attention:
     #   "accurate" two-term P everywhere (about bf16-P accuracy, ~1.5x the matrix work)
     precision = os.getenv("QUANTUM_ATTN_PRECISION", "auto")
 
+    # the P.V product of `fp8_attention_forward` on pre-quantised query / key (the reference's op contract: value arrives in 16 bit):
+    #   "fp8"    (default) value is quantised to fp8 per head and both GEMMs run on FP8 MFMA (north_star)
+    #   "16bit"  the reference kernel's own numerics: 16-bit P on the un-quantised value, bf16 / fp16 MFMA (head_dim 128; about
+    #            1.5x the time).  Independently of this switch the fused step `fp8_attn_func(16-bit q, k, v)` attends the original
+    #            16-bit V for the query blocks that see fewer than 1024 keys (early causal rows, short sequences).
+    pv_precision = os.getenv("QUANTUM_ATTN_PV_PRECISION", "fp8")
+
     # torch.compile: trace the per-head abs-max (and sums of squares) of query / key / value into the caller's graph as aten reductions, so
     # that Inductor fuses them into the kernel that produced the tensors and the quant pre-pass skips its abs-max launch -- what the
     # reference gets from inlining its quantiser into the compiled region (nn.py:410-418, 484-501).  Eager calls are not affected.

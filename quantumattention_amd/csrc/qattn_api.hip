@@ -9,6 +9,7 @@
 #endif
 
 #include "qattn_attn.h"
+#include "qattn_pv16.h"
 
 using namespace qattn;
 
@@ -80,6 +81,7 @@ struct AttnCall {
     float* sq_out;
     int q_numerics;
     int amax_n, amax_stride;
+    const void* v16;              // fused step: the original 16-bit V for the rows that see few keys (else nullptr)
     unsigned long long* stamps;   // measurement entry (else nullptr)
     bool sched_zeroed;            // fused step: the pre-pass has cleared the hand-out counters (else the launch clears them itself)
 };
@@ -96,7 +98,11 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     if (a.D != 64 && a.D != 128 && a.D != 256) return QATTN_ERR_UNSUPPORTED_DIM;  // nn.py:45-49
     if (a.Hq % a.Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;                      // tk/attention.py:398-399
     if (a.qk_fmt != QATTN_FMT_E4M3 && a.qk_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (a.v_fmt != a.qk_fmt) return QATTN_ERR_UNSUPPORTED_FMT;
+    // v_fmt: the fp8 format of q / k (both GEMMs on FP8 MFMA, the main path), or a 16-bit format: v8 is then the caller's ROW-MAJOR
+    // 16-bit V and every row runs the reference's own P.V numerics (qattn_pv16.h); D = 128, no two-term / AUTO machinery involved
+    const bool v_is_16 = a.v_fmt == QATTN_FMT_BF16 || a.v_fmt == QATTN_FMT_FP16;
+    if (!v_is_16 && a.v_fmt != a.qk_fmt) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (v_is_16 && (a.D != 128 || a.q16 != nullptr || a.out_fmt != a.v_fmt)) return QATTN_ERR_UNSUPPORTED_FMT;
     if (a.out_fmt != QATTN_FMT_BF16 && a.out_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
     if (a.scale_mode != QATTN_SCALE_HEAD && a.scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
     if (a.precision != QATTN_PRECISION_AUTO && a.precision != QATTN_PRECISION_FAST && a.precision != QATTN_PRECISION_ACCURATE) return QATTN_ERR_INVALID_ARG;
@@ -144,6 +150,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
     p.q16 = (const unsigned char*)a.q16; p.q_amax_part = a.q_amax_part; p.sq_out = a.sq_out; p.q_numerics = a.q_numerics;
     p.stamp_buf = a.stamps;
+    p.v16 = v_is_16 ? (const unsigned char*)a.v8 : (const unsigned char*)a.v16;
     if (a.stamps && !(a.q16 && attn_v2_covers(a.D, a.is_causal, a.scale_mode) && a.qk_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
     bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
 #ifdef QATTN_DEV
@@ -176,7 +183,8 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     const bool prof = ds != nullptr;
     if (prof) (void)hipEventRecord(ds->prof[0], st);
     int rc;
-    if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
+    if (v_is_16) rc = launch_attn_pv16(p, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
+    else if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     else rc = launch_attn_v4_full(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     if (prof) { (void)hipEventRecord(ds->prof[1], st); ds->recorded = true; }
     if (rc != QATTN_OK) return rc;
@@ -292,6 +300,18 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
                     fprintf(stderr, "[qattn dbg] per-iteration segment cycles (mean of 64 waves): seg0 %.0f | seg1 %.0f | seg2 %.0f | seg3 %.0f | seg4 %.0f | seg5 %.0f\n",
                             tot[0] / iters, tot[1] / iters, tot[2] / iters, tot[3] / iters, tot[4] / iters, tot[5] / iters);
                 }
+                if (p.xcd_remap && !a.is_causal) {   // per XCD (heads are XCD-contiguous): median sweep cycles and in-kernel clock of its waves
+                    char line[512]; int n = 0;
+                    const long per_xcd = n_dbg_waves / 8;
+                    for (int x = 0; x < 8; x++) {
+                        std::vector<double> cy, ck;
+                        for (long i = x * per_xcd; i < (x + 1) * per_xcd; i++) if (h[2 * i + 1]) { cy.push_back((double)h[2 * i]); ck.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
+                        if (cy.empty()) continue;
+                        std::sort(cy.begin(), cy.end()); std::sort(ck.begin(), ck.end());
+                        n += snprintf(line + n, sizeof(line) - n, " x%d %.0fk/%.3f", x, cy[cy.size() / 2] * 1e-3, ck[ck.size() / 2]);
+                    }
+                    fprintf(stderr, "[qattn dbg] per XCD (median sweep kcycles / clock GHz):%s\n", line);
+                }
                 fprintf(stderr, "[qattn dbg] waves=%zu sweep cycles median=%.0f (%.1f per iteration over %d) p10=%.0f p90=%.0f | in-kernel clock median %.3f GHz\n",
                         cyc.size(), cyc[cyc.size() / 2], cyc[cyc.size() / 2] / iters, iters, cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10], clk[clk.size() / 2]);
             }
@@ -373,7 +393,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
     if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
     AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
-               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
+               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
     return attention_impl(a, (hipStream_t)stream, ds);
 }
@@ -442,7 +462,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, stamps, zero_in_prepass};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, fuse_q ? v : nullptr, stamps, zero_in_prepass};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

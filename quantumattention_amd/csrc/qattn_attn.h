@@ -116,6 +116,9 @@ struct AttnParams {
     unsigned* flags; // templated kernel (qattn_attn_v4.hip): one word per (head, 32-row group), set by the one-term launch
     long lse_stride; // floats between the LSE rows of consecutive (b, h)
     float lse_mul;   // 1 (natural log-sum-exp) or -sqrt(D) (QATTN_LSE_REFERENCE)
+    // The ORIGINAL 16-bit V, row-major [B,Hkv,Skv,D] (else nullptr): what pv16_block_pass (qattn_pv16.h) attends -- every block of a
+    // call with v_fmt = QATTN_FMT_BF16 / _FP16, and in the fused step the blocks that see fewer than two_term_keys keys (bf16)
+    const unsigned char* v16;
     const unsigned char* q16;      // fused step: the 16-bit (bf16) Q tensor, quantised row by row in the kernel prologue (else nullptr)
     const unsigned* q_amax_part;   // fused step: abs-max words (fp32 bits) of every q head, [B*Hq][amax_stride], amax_n valid per head:
     int amax_n, amax_stride;       //   the abs-max pass's per-block words, or ONE caller-supplied word per head (producer hand-off)

@@ -1,0 +1,38 @@
+// qattn_attn_pv16.hip -- qattn_fp8_attention_forward with a 16-bit V (v_fmt = QATTN_FMT_BF16 / QATTN_FMT_FP16): the reference kernel's
+// own numerics (FP8 QK^T, 16-bit P and V: src/quantum_attn/tk/attention.py:72,286,318) for whole tensors.  Every 256-row query block
+// runs pv16_block_pass (qattn_pv16.h); the fused step reaches the same pass from inside the D = 128 kernel for its early rows.
+#include "qattn_pv16.h"
+
+namespace qattn {
+
+template <int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN>
+__global__ __launch_bounds__(kThreads, 2) void attn_pv16_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pv16_block_pass<128, kWaves, QK_FMT, V16_FMT, CAUSAL, TOKEN, false>(p, smem, (int)threadIdx.x, (int)blockIdx.x);
+}
+
+template <int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN>
+static int launch_one(const AttnParams& p, hipStream_t st) {
+    constexpr int lds = kPv16Slots * (64 * 128 + 64 * 128 * 2);
+    auto kern = attn_pv16_kernel<QK_FMT, V16_FMT, CAUSAL, TOKEN>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QATTN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.Hq * p.nqb)), dim3(kThreads), lds, st, p);
+    return QATTN_OK;
+}
+
+template <int QK_FMT, int V16_FMT>
+static int launch_fmt(const AttnParams& p, int causal, int scale_mode, hipStream_t st) {
+    const bool tok = scale_mode == QATTN_SCALE_TOKEN;
+    if (causal) return tok ? launch_one<QK_FMT, V16_FMT, true, true>(p, st) : launch_one<QK_FMT, V16_FMT, true, false>(p, st);
+    return tok ? launch_one<QK_FMT, V16_FMT, false, true>(p, st) : launch_one<QK_FMT, V16_FMT, false, false>(p, st);
+}
+
+int launch_attn_pv16(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st) {
+    if (qk_fmt == QATTN_FMT_E4M3)
+        return v16_fmt == QATTN_FMT_BF16 ? launch_fmt<QATTN_FMT_E4M3, QATTN_FMT_BF16>(p, causal, scale_mode, st)
+                                         : launch_fmt<QATTN_FMT_E4M3, QATTN_FMT_FP16>(p, causal, scale_mode, st);
+    return v16_fmt == QATTN_FMT_BF16 ? launch_fmt<QATTN_FMT_E5M2, QATTN_FMT_BF16>(p, causal, scale_mode, st)
+                                     : launch_fmt<QATTN_FMT_E5M2, QATTN_FMT_FP16>(p, causal, scale_mode, st);
+}
+
+}  // namespace qattn

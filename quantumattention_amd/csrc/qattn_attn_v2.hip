@@ -40,6 +40,7 @@
 #include <type_traits>
 
 #include "qattn_attn.h"
+#include "qattn_pv16.h"
 
 namespace qattn {
 
@@ -522,6 +523,22 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         st.vpre[1] = lds_read_frag(kbuf + CH + (1 << 11));
         advance();
     }
+    // The row's reference starts at chunk 0's maximum.  Left at the -1e30 sentinel, the first full step always took the fix-up
+    // branch: 64 multiplications of an all-zero O^T by alpha = 0 and a second pass over the chunk's exponentials, with every wave of
+    // the workgroup in it at once (nothing on the matrix pipe meanwhile) -- once per block.  Setting m_run / mcv / lim here with the
+    // branch's own expressions gives the same bits: the first step's optimistic exponentials ARE the branch's recomputed ones.
+    if constexpr (!TOKEN && (ABL & 4) == 0) {   // (token-wise key scales are applied by prep_scores, which must then run once per chunk)
+        constexpr float SHIFT = BYTE ? kPShiftByte : kPShift, THR = BYTE ? kRescaleThrByte : kRescaleThr;
+        constexpr float U16 = (ABL & 32) ? 1.0f : 1.0f / 65535.0f;
+        prep_scores<CAUSAL, TOKEN, true>(st.s[0][0], st.s[0][1], p, 0, q0, qrow, hh, skt);   // (idempotent: the first step masks chunk 0 again)
+        float mx0 = max32_after_mfma(st.s[0][0], st.s[0][1]);
+        const auto sw0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx0), __float_as_uint(mx0), false, false);
+        mx0 = fmaxf(__uint_as_float(sw0[0]), __uint_as_float(sw0[1]));
+        const float m_new = fmaxf(st.m_run, mx0);
+        st.m_run = m_new;
+        st.mcv = BYTE ? __builtin_fmaf((-8.0f * U16) * m_new, st.c, (8.0f * SHIFT + 56.0f + kByteBias) * U16) : SHIFT - m_new * st.c;
+        st.lim = m_new + THR / st.c;
+    }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
     constexpr bool FORECAST = !TOKEN && !TWO && BYTE && (ABL & ~(512 | 1024)) == 0;   // (run-time: only passes that check their rows ask for it)
@@ -963,6 +980,20 @@ template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BY
 __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char* smem, int bid, int tid) {   // tid: an opaque copy of threadIdx.x
     int head, qb;
     map_block(p, bid, p.nqb, CAUSAL, head, qb);
+    // Fused step (the original bf16 V is at hand): a block whose first row sees fewer than two_term_keys keys -- early causal rows, short
+    // sequences -- runs the reference kernel's own P.V numerics, 16-bit P on the un-quantised V (qattn_pv16.h), instead of two-term fp8
+    // P on the fp8 V: row 0 of a causal head IS V[0], and an fp8 V puts its rounding error (up to 2^-4 relative) straight into the output.
+    // The same MFMA time as the two-term pass (16 bf16 products of 32 cycles for 8 fp8 products of 64), fewer VALU instructions.
+    if constexpr (Q16 && NW == 8) {
+        if (p.v16 != nullptr) {
+            const int nkeys0 = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;
+            if (nkeys0 < p.two_term_keys) {   // workgroup-uniform
+                asm volatile("" : "+v"(tid));
+                pv16_block_pass<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL, false, true>(p, smem, tid, bid);
+                return 0u;
+            }
+        }
+    }
     // One copy of each pass.  Every per-lane value is re-derived inside block_pass from an opaque copy of the thread index, so
     // nothing of the one-term pass stays live in registers across the two-term loop (and vice versa).
     bool two = p.n_two != 0;  // workgroup-uniform; n_two = nqb: every block (QATTN_PRECISION_ACCURATE)

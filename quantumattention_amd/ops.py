@@ -97,8 +97,14 @@ def fp8_attention_forward(
         raise RuntimeError(reason)
     scaling = "head-wise" if scale_q.dim() == 2 else "token-wise"
     k_frag = _native.pack_fp8(key, _native.LAYOUT_KFRAG)
-    v_frag, scale_v = _native.quant_fp8(value, scaling="head-wise", fp8_dtype=query.dtype,
-                                        layout=_native.LAYOUT_VFRAG)
+    if config.attention.pv_precision == "16bit" and D == 128:
+        # the reference kernel's own numerics: value stays 16-bit, P is cast to 16 bit (tk/attention.py:72,286,318)
+        v_frag, scale_v = value, None
+    else:
+        if config.attention.pv_precision not in ("fp8", "16bit"):
+            raise ValueError(f"Unsupported config.attention.pv_precision: {config.attention.pv_precision!r} (expected 'fp8' or '16bit')")
+        v_frag, scale_v = _native.quant_fp8(value, scaling="head-wise", fp8_dtype=query.dtype,
+                                            layout=_native.LAYOUT_VFRAG)
     return _native.fp8_attention_forward(
         query, k_frag, v_frag, scale_q, scale_k, scale_v, Hkv=Hkv, Skv=Skv, out_dtype=value.dtype,
         is_causal=is_causal, scaling=scaling, sm_scale=0.0 if scale is None else float(scale),

@@ -414,8 +414,12 @@ def test_compiled_producer_fuses_the_abs_max_and_skips_the_pre_pass_launch(preci
     B, H, S, D = 2, 8, 2048, 128
 
     def f(x, wk, v):
-        q = (x * 1.25).to(torch.bfloat16)           # stand-ins for a projection / RoPE epilogue
-        k = (wk + 0.5 * wk.roll(1, -1)).to(torch.bfloat16)
+        # stand-ins for a projection / RoPE epilogue whose results are EXACT in bf16 (a power-of-two factor, a sign flip, a rotation), so
+        # that eager and Inductor produce the same q and k bits: with an inexact producer Inductor reduces over its un-rounded fp32
+        # intermediate (no bf16 round trip inside a fused kernel), and the abs-max -- hence the scale -- may differ from eager's in
+        # the last bit, exactly as the reference's compiled quantiser differs from its eager one
+        q = x * 0.5
+        k = -wk.roll(1, -1)
         return qa.fp8_attn_func(q, k, v, is_causal=True)
 
     x, wk, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
