@@ -134,6 +134,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.peak_r0 = a.precision == QATTN_PRECISION_AUTO ? kPeakR0 : 0.0f;
     p.peak_neff = a.precision == QATTN_PRECISION_AUTO ? kPeakNeff : 0.0f;
     p.max_rescue = kMaxRescueWaves;
+    p.max_rescue_rows = kMaxRescueRows;
     p.persistent = 1;
     p.dyn_min_rounds = kDynMinRounds;
     p.no_forecast = 0;
@@ -160,6 +161,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = getenv("QATTN_PEAK_R0") ? (float)atof(getenv("QATTN_PEAK_R0")) : e.peak_r0;   // (read per call: tools/ab.py variants)
     if (a.precision == QATTN_PRECISION_AUTO && getenv("QATTN_PEAK_NEFF")) p.peak_neff = (float)atof(getenv("QATTN_PEAK_NEFF"));
     if (getenv("QATTN_MAX_RESCUE")) p.max_rescue = atoi(getenv("QATTN_MAX_RESCUE"));
+    if (getenv("QATTN_MAX_RESCUE_ROWS")) p.max_rescue_rows = atoi(getenv("QATTN_MAX_RESCUE_ROWS"));
     if (getenv("QATTN_PERSISTENT")) p.persistent = atoi(getenv("QATTN_PERSISTENT"));
     if (getenv("QATTN_NO_SCHED")) p.sched = nullptr;   // static block order, rescues on the spot (round 2's behaviour)
     if (getenv("QATTN_NO_RISKY")) p.risky_lo = p.risky_hi = 0;   // plain longest-first causal order

@@ -52,6 +52,18 @@ __device__ inline float predicted_r(float nkeys, float var, float z) {
     asm volatile("" : "+v"(half));
     return nkeys * __expf(half * var - z * sqrtf(var));
 }
+// "So many rows of a block will end peaked that the block should run two-term from the start": rows, gathered across the waves of a
+// block, are the unit of the rescue (rescue_pass), and recomputing g groups of 32 costs about 0.28 g sweeps against 1.8 for the two-term
+// sweep -- worth it up to about a third of the block's rows.  For scores ~ N(0, var) over n keys a row ends with R < kPeakR0 when its
+// largest score sits more than z* standard deviations out, n exp(var / 2 - z* sigma) = kPeakR0 (predicted_r), which happens to a
+// fraction n (1 - Phi(z*)) of the rows; that fraction is 0.35 at z* = sqrt(2 ln n) - 0.38 (3.34 / 3.70 / 4.03 at n = 1024 / 4096 /
+// 16384).  Second criterion: the effective key count n exp(-var) of such rows falls below kPeakNeff (with a margin) -- then EVERY row
+// is flagged whatever its largest weight (score spread >= 1.7 at n = 4096).
+constexpr float kNeffStartMargin = 1.25f;
+__device__ inline bool many_rows_peaked(float nkeys, float var) {
+    const float z_many = sqrtf(2.0f * __logf(fmaxf(nkeys, 2.0f))) - 0.38f;
+    return predicted_r(nkeys, var, z_many) < kPeakR0 || nkeys * __expf(-var) < kNeffStartMargin * kPeakNeff;
+}
 // a head's sum of squares from its partial sums, the same value in every lane of every wave (fixed order: lane l adds
 // l, l + 64, ...; then a fixed reduction tree)
 __device__ inline float sum_partials(const float* part, int n, int lane) {
@@ -112,6 +124,7 @@ struct AttnParams {
     int sched_nq;                // block counters in use: 8 (one per XCD label blockIdx.x & 7) with xcd_remap, else 1
     int no_forecast;             // dev switch
     const unsigned* vexp;        // fused step with a block-scaled V (else nullptr): E8M0 byte of every 64-key V chunk, [B*Hkv][ssq_stride]
+    int max_rescue_rows;         // D = 128 kernel: more peaked ROWS than this in a 256-row block: the block is redone in two-term mode (fewer: gathered and rescued)
     int max_rescue;              // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
     unsigned* flags; // templated kernel (qattn_attn_v4.hip): one word per (head, 32-row group), set by the one-term launch
     long lse_stride; // floats between the LSE rows of consecutive (b, h)
@@ -162,10 +175,12 @@ inline hipError_t zero_words(unsigned* w, long n, hipStream_t st) {
 }
 
 #define QATTN_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-// the next block of queue x, else of another queue (a workgroup that has finished its XCD's blocks helps elsewhere); -1: none left
-__device__ inline int sched_next_block(SchedState* s, int nq, int x, int bpq, int first) {
+// the next block of queue x, else of another queue (a workgroup that has finished its XCD's blocks helps elsewhere); -1: none left.
+// Two halves, so that a caller can put work between the request and its use: sched_draw_issue returns the raw ticket of queue x.
+__device__ inline unsigned sched_draw_issue(SchedState* s, int x) { return __hip_atomic_fetch_add(&s->next[x], 1u, QATTN_RLX_AGENT); }
+__device__ inline int sched_draw_finish(SchedState* s, int nq, int x, int bpq, int first, unsigned ticket) {
     // (unsigned comparisons: whatever the counters hold, a block number outside [0, bpq * nq) is never handed out)
-    const unsigned idx = __hip_atomic_fetch_add(&s->next[x], 1u, QATTN_RLX_AGENT) + (unsigned)first;
+    const unsigned idx = ticket + (unsigned)first;
     if (idx < (unsigned)bpq) return (int)idx * nq + x;
     unsigned nx[8];
 #pragma unroll
@@ -178,6 +193,9 @@ __device__ inline int sched_next_block(SchedState* s, int nq, int x, int bpq, in
         if (j < (unsigned)bpq) return (int)j * nq + xx;
     }
     return -1;
+}
+__device__ inline int sched_next_block(SchedState* s, int nq, int x, int bpq, int first) {
+    return sched_draw_finish(s, nq, x, bpq, first, sched_draw_issue(s, x));
 }
 
 // The verdict on one row at the end of a one-term sweep.  l = sum P', l2 = sum P'^2 (BYTE: kNeffByteRatio of
@@ -472,7 +490,8 @@ __device__ __forceinline__ void prep_scores(v16f& s0, v16f& s1, const AttnParams
 // rescue_groups_kernel for the templated kernel's launches; the Q^T fragments come from global memory through `qfrag`.
 // About 0.3 of a 256-row block's sweep.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kMaxRescueWaves = 2;   // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode
+constexpr int kMaxRescueWaves = 2;   // (templated kernel) more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode
+constexpr int kMaxRescueRows = 96;   // (D = 128 kernel) more peaked rows than this in a 256-row block: redone; else gathered into <= 3 groups of 32 and recomputed
 
 __device__ __forceinline__ v8i gload_frag(const unsigned char* base) {
     const v4i lo = *reinterpret_cast<const v4i*>(base);
@@ -486,10 +505,14 @@ __device__ __forceinline__ v8i gload_frag(const unsigned char* base) {
 template <int D>
 constexpr int rescue_slot_bytes() { return ((D / 32) * 16 + 2) * 64 * 4; }   // one wave's partial {O^T, m, l}
 
+// The 32 rows are ANY rows of one head, one per lane pair (lanes l and l + 32): `row` (per lane; c and qfrag belong to it), of which
+// the lanes with `store` set are written; row_lo / row_hi (wave-uniform) bound the rows for the causal chunk count and the mask test.
+// The D = 128 kernel passes the flagged rows of a 256-row block, gathered from all its waves (rescue_pass); the wrapper below is the
+// contiguous group r0 .. r0 + 31 of the templated kernel's rescue launch.
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QLDS = false, bool VSCALE = false, typename QFrag>
-__device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
-                                            int r0, int wave, int lane, long bh, long kv_head, float c, const float* skt, QFrag&& qfrag,
-                                            const unsigned* vx = nullptr) {   // vx: the V chunks' scale bytes (LDS), nullptr: unscaled V
+__device__ __forceinline__ void rescue_rows_at(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
+                                               int row, bool store, int row_lo, int row_hi, int wave, int lane, long bh, long kv_head, float c,
+                                               const float* skt, QFrag&& qfrag, const unsigned* vx = nullptr) {   // vx: the V chunks' scale bytes (LDS), nullptr: unscaled V
     static_assert(NW == 8, "three merge rounds");
     constexpr int CH = 64 * D, KS = D / 64, MB = D / 32;
     constexpr int SLOT = rescue_slot_bytes<D>();
@@ -497,14 +520,14 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
                                                // O^T; QLDS: the caller's qfrag reads LDS, cheap enough to repeat per chunk)
     constexpr int VB = MB > 4 ? 2 : MB;   // V fragments requested ahead of the PV MFMAs
     const int ql = lane & 31, hh = lane >> 5;
-    const int row = r0 + ql;
+    const int r0 = row_lo;   // (the mask test below: chunks that end at or before the group's first row need no causal mask)
     const int frag_lane_off = (hh << 10) + (ql << 4);
     v8i qf[QPRE ? KS : 1];
     if (QPRE) {
 #pragma unroll
         for (int s = 0; s < KS; s++) qf[s] = qfrag(s);
     }
-    const int n_r = CAUSAL ? min(p.nchunks, (min(r0 + kQPerWave, p.Sq) - 1) / 64 + 1) : p.nchunks;
+    const int n_r = CAUSAL ? min(p.nchunks, min(row_hi, p.Sq - 1) / 64 + 1) : p.nchunks;
     const int per = (n_r + NW - 1) / NW;
     const int t0 = wave * per, t1 = min(n_r, t0 + per);
     v16f o[MB];
@@ -642,10 +665,18 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         const float sv = p.sv ? p.sv[kv_head] : 1.0f;
-        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + row, hh, row < p.Sq);
-        if (p.lse && hh == 0 && row < p.Sq)
+        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + row, hh, store && row < p.Sq);
+        if (p.lse && hh == 0 && store && row < p.Sq)
             p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
     }
+}
+
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QLDS = false, bool VSCALE = false, typename QFrag>
+__device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
+                                            int r0, int wave, int lane, long bh, long kv_head, float c, const float* skt, QFrag&& qfrag,
+                                            const unsigned* vx = nullptr) {
+    rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, QLDS, VSCALE>(p, smem, kg, vg, r0 + (lane & 31), true, r0, r0 + kQPerWave - 1, wave, lane, bh, kv_head, c,
+                                                                     skt, qfrag, vx);
 }
 
 // kernel-file entry points (one translation unit per operand format / head dimension, see build.py)

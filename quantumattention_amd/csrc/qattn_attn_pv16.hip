@@ -8,7 +8,7 @@ namespace qattn {
 template <int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN>
 __global__ __launch_bounds__(kThreads, 2) void attn_pv16_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pv16_block_pass<128, kWaves, QK_FMT, V16_FMT, CAUSAL, TOKEN, false>(p, smem, (int)threadIdx.x, (int)blockIdx.x);
+    pv16_block_pass<128, kWaves, QK_FMT, V16_FMT, CAUSAL, TOKEN, false>(p, smem, (int)threadIdx.x, (int)blockIdx.x, []() { return 0u; }, [](unsigned) {});
 }
 
 template <int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN>

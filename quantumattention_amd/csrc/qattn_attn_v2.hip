@@ -398,12 +398,16 @@ __device__ __forceinline__ void stage_dma8(const unsigned char* kg, const unsign
 // going to be repeated in two-term mode anyway: after two more chunks (the votes travel through the sweep's own barrier) all
 // waves drain the ring, stop and return true -- 3 of n chunks wasted instead of all of them.  Chunk 0 stands for the whole
 // key range here; where it does not, the R test at the end of the sweep is still the arbiter.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, typename LoadQ>
+// `prefetch` (NPF > 0: non-causal one-term passes): called once, two or three iterations before the sweep ends, it may request the NEXT
+// block's Q rows -- NPF LDS-DMA pieces per wave into a dump slot nobody reads, which leaves the rows in this XCD's L2 -- and says
+// whether it did; the sweep's remaining waits then leave those NPF youngest requests in flight (s_waitcnt vmcnt(NPF): the counter is in
+// order and no K/V stage is requested after this point of a non-causal sweep).
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, int NPF = 0, typename LoadQ, typename Prefetch>
 __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q,
-                                         bool forecast = false, unsigned* vote = nullptr, const unsigned* vx = nullptr,   // vx (VS): the V chunks' scale bytes in LDS
-                                         bool first_stages_issued = false) {   // the caller has requested stages 0 .. kSyncEvery - 1 already
+                                         bool forecast, unsigned* vote, const unsigned* vx,   // vx (VS): the V chunks' scale bytes in LDS
+                                         bool first_stages_issued, Prefetch&& prefetch) {   // first_stages_issued: the caller has requested stages 0 .. kSyncEvery - 1 already
     constexpr int CH = 64 * D, STAGE = 2 * CH;
     const int hh = lane >> 5;
     const int T = n_wg + 2;  // iterations t = 0 .. n_wg+1 : QK(t), softmax(t-1), PV(t-2)
@@ -474,6 +478,23 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         }
         return smem + slot_cur + frag_lane_off;
     };
+    // the same for the last iterations of a sweep whose caller may have requests of its own in flight (see `prefetch` above)
+    static_assert(NPF == 0 || !CAUSAL, "a causal sweep requests K/V stages to its end");
+    bool pf_issued = false;
+    auto sync_tail = [&](int t) __attribute__((always_inline)) -> const unsigned char* {
+        if constexpr (NPF == 0) return sync_iter(t, true);
+        else {
+            if (t % kSyncEvery == 0) {
+                if (pf_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                // (t + kSyncEvery >= T here: nothing left to request)
+            } else {
+                asm volatile("s_nop 0" ::: "memory");
+            }
+            return smem + slot_cur + frag_lane_off;
+        }
+    };
     auto advance = [&]() __attribute__((always_inline)) {  // slot_cur / slot_prev: LDS offsets of stage(t) / stage(t-1), advanced once per iteration
         slot_prev = slot_cur;
         slot_cur = slot_cur + STAGE == kStagesV2 * STAGE ? 0u : slot_cur + STAGE;
@@ -488,7 +509,8 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     auto full = [&](auto par_tag, int t, auto ragged_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool RAGGED = decltype(ragged_tag)::value;
-        const unsigned char* kbuf = sync_iter(t, true);
+        const unsigned char* kbuf;
+        if constexpr (NPF > 0 && RAGGED) kbuf = sync_tail(t); else kbuf = sync_iter(t, true);   // (non-causal: RAGGED marks the sweep's last iterations)
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         advance();
         QATTN2_STAMP(0);
@@ -563,7 +585,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
             const float var = fmaxf(sq * (1.0f / 2048.0f) - mean * mean, 0.0f) * cn * cn;
             const int nkeys = CAUSAL ? min(p.Skv, q0 + kQPerWave) : p.Skv;
             // (below the dead band the block already started in the right mode: borderline causal rows are cheaper to rescue)
-            const bool mine = var >= kVarDeadband && predicted_r((float)nkeys, var, kPeakZWide) < kPeakR0;   // the same value in every lane
+            const bool mine = var >= kVarDeadband && many_rows_peaked((float)nkeys, var);   // the same value in every lane
             if (lane == 0) vote[wave] = mine ? 1u : 0u;
         }
     }
@@ -580,7 +602,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
                 int nf = 0;
 #pragma unroll
                 for (int w = 0; w < NW; w++) nf += vote[w] != 0u ? 1 : 0;
-                if (__builtin_amdgcn_readfirstlane(nf) > p.max_rescue) {
+                if (__builtin_amdgcn_readfirstlane(nf) * 2 > NW) {   // most waves expect more peaked rows than a rescue is worth
                     wait_vmcnt<0>();   // the stages requested at that barrier
                     __builtin_amdgcn_s_barrier();
                     return true;
@@ -588,6 +610,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
             }
         }
     }
+    if constexpr (NPF > 0) pf_issued = prefetch();   // (every K/V stage of the sweep has been requested by now)
     for (; t + 1 <= n_w; t += 2) {  // at most one trip
         full(P1{}, t, Last{});
         full(P0{}, t + 1, Last{});
@@ -598,7 +621,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // t = n_w + 1: the last chunk's PV (V(t-2) lives in stage(t-1); its row blocks 0,1 are already in vpre)
     {
-        (void)sync_iter(t);
+        if constexpr (NPF > 0) (void)sync_tail(t); else (void)sync_iter(t);
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         const v8i fc = lds_read_frag(vprev + (2 << 11)), fd = lds_read_frag(vprev + (3 << 11));
         // (VS: st.vsx already holds the scale of V(t - 2) = V(n_w - 1), requested by the last full step)
@@ -629,17 +652,36 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     return false;
 }
 
+// The next block of a dynamic launch is requested when the block's KV sweep is over, BEFORE its rows are normalised and stored, and
+// taken delivery of behind those stores (thread 0; `mail`: the LDS word the workgroup reads after the block's end barrier, nullptr:
+// static launch or not the block's first pass).  Requested after the stores -- round 3 -- the atomic sat behind their write
+// acknowledgements (one counter) with every wave waiting at the hand-over barrier: 1.2 .. 2 us per block in the dev work log of a C3
+// launch.  Requested in the block's PROLOGUE (measured this round, profiles/r04/ab_c3_draw_in_prologue_dropped.log) the round trip
+// is free but a workgroup then holds a reserved block for the length of a whole block: C3 +1.4 %, C5 +1.6 % (idle time before the end
+// of a C3 launch 21 -> 35 us).
+__device__ __forceinline__ unsigned draw_issue(const AttnParams& p, volatile unsigned* mail, int tid) {
+    unsigned ticket = 0u;
+    if (mail != nullptr && tid == 0) ticket = sched_draw_issue(p.sched, (int)blockIdx.x & (p.sched_nq - 1));
+    return ticket;
+}
+__device__ __forceinline__ void draw_finish(const AttnParams& p, volatile unsigned* mail, int tid, unsigned ticket) {
+    if (mail != nullptr && tid == 0) {
+        const int nq = p.sched_nq;
+        lds_write_word_raw(mail, (unsigned)sched_draw_finish(p.sched, nq, (int)blockIdx.x & (nq - 1), p.total_blocks / nq, (int)gridDim.x / nq, ticket));
+    }
+}
+
 // One pass of a wave over its KV range with P in TWO (hi + lo) or one term, BYTE-exponential or exact, followed by the
 // row sums.  With `check_peaked`, rows of the WORKGROUP that turned out peaked (largest softmax weight 1 / R above
 // 1 / peak_r0) make it return, workgroup-uniform: kPassRedo -- too many, nothing of the flagged waves is stored, the
 // caller repeats the block in two-term mode -- or the bit mask of the (at most max_rescue) waves whose 32-row groups
 // rescue_pass then recomputes; the other waves' rows (and the optional LSE) are stored.  0: everything is stored.
 constexpr int kPassRedo = 1 << 30;
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, bool NEFF = false, typename LoadQ>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, bool NEFF = false, int NPF = 0, typename LoadQ, typename Prefetch>
 __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
                                              int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q,
-                                             const unsigned* vx = nullptr, bool first_stages_issued = false) {
+                                             const unsigned* vx, bool first_stages_issued, volatile unsigned* mail, Prefetch&& prefetch) {
     constexpr int MB = D / 32;
     const int hh = lane >> 5;
     WaveState<D, TWO, BYTE> st;
@@ -679,9 +721,13 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
         }
     };
-    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
-                                                                                !TWO && check_peaked, vote, vx, first_stages_issued))
-        return kPassRedo;   // forecast: the block is peaked, nothing was stored
+    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF, NPF>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
+                                                                                     !TWO && check_peaked, vote, vx, first_stages_issued, prefetch))
+    {   // forecast: the block is peaked, nothing was stored (its successor is drawn here: the repeated pass draws nothing)
+        const int t_ = (wave << 6) | lane;
+        draw_finish(p, mail, t_, draw_issue(p, mail, t_));
+        return kPassRedo;
+    }
     if constexpr ((ABL & 1024) != 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0 && p.stamp_buf) {
@@ -708,6 +754,8 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
 #endif
     const float m_run = st.m_run, l_run = st.l_run;
     v16f (&o)[MB] = st.o;
+    const int tid_draw = (wave << 6) | lane;
+    const unsigned ticket = draw_issue(p, mail, tid_draw);   // (a forecast exit above draws in the repeated pass instead)
 
     // ---- combine the two half-wave partial sums
     float l_tot, l2_tot = 0.0f;   // l2_tot: sum of P'^2 (exact mode) or kNeffByteRatio of it (BYTE)
@@ -738,41 +786,49 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             d[0] = l_tot; d[1] = st.m_true; d[2] = m_run; d[3] = c;
         }
 #endif
-        // per-wave votes -> the set of waves of this workgroup that hold a peaked row (workgroup-uniform after the barrier)
+        // per-wave masks of the peaked ROWS (both half-waves reach the same verdict: bit r = the wave's row r) -> after the barrier every
+        // wave knows how many rows of the block need help.  Few: they are gathered across the waves into dense 32-row groups and
+        // recomputed (rescue_pass); many: the block repeats in two-term mode.  Rows, not 32-row groups, are the unit: on data with a
+        // score spread of 1.2 .. 1.6 about 1 .. 6 % of the rows end peaked -- a handful per block, but spread over most of its eight
+        // groups, which used to send nearly every such block into the two-term repeat.
 #ifdef QATTN_DEV
-        const bool mine = p.peak_r0 > 1.0e6f ? wave == 0 : __any(peaked) != 0;   // QATTN_PEAK_R0=1e7: rescue wave 0 of every block (timing)
+        const unsigned mine = p.peak_r0 > 1.0e6f ? (wave == 0 ? 1u : 0u) : (unsigned)__ballot(peaked);   // QATTN_PEAK_R0=1e7: rescue row 0 of every block (timing)
+        const bool keep = p.peak_r0 > 1.0e6f ? !(wave == 0 && (lane & 31) == 0) : !peaked;
 #else
-        const bool mine = __any(peaked) != 0;
+        const unsigned mine = (unsigned)__ballot(peaked);   // (low word: lanes 0 .. 31)
+        const bool keep = !peaked;
 #endif
-        // a wave without a peaked row stores its rows right away (under the other waves' last iterations, as in the unchecked
-        // kernel); only then does it meet the others to learn whether some wave needs the workgroup's help
+        // every row that is final is stored right away (under the other waves' last iterations, as in the unchecked kernel); the
+        // peaked ones are left to whoever recomputes them -- a second store to the same address from another wave is not ordered
+        // behind this one
         const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
-        if (!mine) {
-            store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq);
-            if (p.lse && hh == 0 && qrow < p.Sq)
-                p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
-        }
+        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq && keep);
+        if (p.lse && hh == 0 && qrow < p.Sq && keep)
+            p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
+        draw_finish(p, mail, tid_draw, ticket);
         static_assert(NW <= 8, "eight vote words");
-        if (lane == 0) lds_write_word_raw(vote + wave, mine ? 1u : 0u);
+        if (lane == 0) lds_write_word_raw(vote + wave, mine);
         lds_barrier();   // also: every wave is done with the K/V ring (the O rows just stored are nobody else's business)
-        unsigned flagged = 0;
+        int nrows = 0;
         {
             v4i va, vb;
             lds_read_8words_raw(vote, va, vb);
 #pragma unroll
-            for (int w = 0; w < NW; w++) flagged |= ((w < 4 ? va[w & 3] : vb[w & 3]) != 0 ? 1u : 0u) << w;
+            for (int w = 0; w < NW; w++) nrows += __builtin_popcount((unsigned)(w < 4 ? va[w & 3] : vb[w & 3]));
         }
-        flagged = __builtin_amdgcn_readfirstlane(flagged);
-        const int nf = __builtin_popcount(flagged);
-        if (nf > p.max_rescue) return kPassRedo;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
-        if constexpr (!TOKEN && NW == 8) return (int)flagged;   // 0: done; else the waves whose 32-row groups rescue_pass recomputes
-        return nf > 0 ? kPassRedo : 0;
+        nrows = __builtin_amdgcn_readfirstlane(nrows);
+        if (nrows == 0) return 0;
+        if constexpr (!TOKEN && NW == 8) {
+            if (nrows <= p.max_rescue_rows) return nrows;   // rescue_pass gathers them from the vote words
+        }
+        return kPassRedo;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
     }
 
     // ---- normalise, convert, store
     const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
     const float inv = sv / l_tot;
     store_o_rows<MB>(p.out, p.out_fmt, o, inv, bh * p.Sq + qrow, hh, qrow < p.Sq);
+    draw_finish(p, mail, tid_draw, ticket);
     if (qrow < p.Sq) {
         if (p.lse && hh == 0) {
             // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l'); QATTN_LSE_REFERENCE: the reference's (disabled) vector
@@ -787,7 +843,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
 // Everything a wave derives from its thread / block index for one pass over its query rows, and that pass itself (the Q^T
 // fragments are re-loaded by a second pass: a few KiB against the pass's megabytes of K / V).
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16, bool NEFF = false>
-__device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked) {
+__device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked, volatile unsigned* mail = nullptr) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
     constexpr int KS = D / 64;      // QK^T k-steps
@@ -904,8 +960,34 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     };
     // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
     constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
-    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO && !(ABL & 512)>(   // (ABL 512: dev timing of the statistic's cost)
-        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst);
+    // Static non-causal launches know their next block (bid + grid): near the end of the sweep every wave asks for ITS 32 rows of that
+    // block's Q -- 8 KiB of bf16 (fused step) or 4 KiB of fp8, read exactly once and therefore never in a cache -- by LDS-DMA into a 1 KiB
+    // dump slot behind the V scale words.  Nothing reads the slot; the point is that the rows then sit in this XCD's L2 when the next
+    // block's prologue asks for them in earnest: that request is the longest wait of a block's prologue (dev timeline: prologue 2.9 us
+    // of a 65 us block) and no register survives the block boundary for it (round 3's register prefetch: +25 registers, spills).
+    constexpr int NPF = (!CAUSAL && !TWO && BYTE && !TOKEN && NW == 8 && ABL == 0) ? (Q16 ? 8 : 4) : 0;
+    auto prefetch_next = [&]() -> bool {
+        if constexpr (NPF == 0) return false;
+        else {
+            const int nb = bid + (int)gridDim.x;
+            if (p.sched != nullptr || nb >= p.total_blocks) return false;   // dynamic hand-out / last round (workgroup-uniform)
+            int head2, qb2;
+            map_block(p, nb, p.nqb, false, head2, qb2);
+            constexpr int RB = Q16 ? 2 * D : D;          // bytes per Q row
+            constexpr int RPP = 1024 / RB;               // rows per 1 KiB piece
+            const unsigned char* qsrc = Q16 ? p.q16 : p.q;
+            unsigned char* dump = smem + kStagesV2 * STAGE + NW * kQPerWave * D + 64 + 4 * kVxWords;
+#pragma unroll
+            for (int j = 0; j < NPF; j++) {
+                const int r = min(qb2 * QWG + wave * kQPerWave + j * RPP + lane / (RB / 16), p.Sq - 1);
+                const unsigned char* src = qsrc + ((long)head2 * p.Sq + r) * RB + (lane % (RB / 16)) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dump, 16, 0, 0);
+            }
+            return true;
+        }
+    };
+    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO && !(ABL & 512), NPF>(   // (ABL 512: dev timing of the statistic's cost)
+        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst, mail, prefetch_next);
 }
 
 // The rescue of a block's flagged 32-row groups as a pass of its own, run by whichever workgroup took the queue item (or by the
@@ -913,8 +995,17 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
 // that nothing of a sweep is live here and nothing of this is live in a sweep.  The rescued rows' Q^T fragments are fetched
 // from global memory (fused step: the 16-bit rows, quantised with the quant8 sequence of the sweep's prologue: the same
 // bytes), the head's V chunk scales are re-read into LDS; the K/V ring is idle and holds the prefetch and the merge.
+// The e-th set bit of m (e < popcount(m)): five halving steps on prefix popcounts.
+__device__ __forceinline__ int select_bit(unsigned m, int e) {
+    int pos = 0;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 1)
+        if (__builtin_popcount(m & ((1u << (pos + step)) - 1u)) <= e) pos += step;
+    return pos;
+}
+
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool Q16>
-__device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, unsigned flagged) {
+__device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, int nrows) {   // nrows: set bits of the block's vote words
     constexpr int CH = 64 * D;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -937,8 +1028,32 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     } else {
         c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
     }
-    for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
-        const int r0 = qb * (NW * kQPerWave) + __builtin_ctz(rest) * kQPerWave, row = r0 + ql;
+    // the block's peaked rows, wave after wave in row order, 32 per group: lane pair ql takes entry 32 g + ql (a group's spare lanes
+    // recompute its first row and store nothing)
+    unsigned masks[NW];
+    {
+        const volatile unsigned* vote = reinterpret_cast<const volatile unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D);
+        v4i va, vb;
+        lds_read_8words_raw(vote, va, vb);
+#pragma unroll
+        for (int w = 0; w < NW; w++) masks[w] = (unsigned)(w < 4 ? va[w & 3] : vb[w & 3]);
+    }
+    for (int g0 = 0; g0 < nrows; g0 += kQPerWave) {
+        const bool have = g0 + ql < nrows;
+        int e = have ? g0 + ql : g0, wsel = 0;
+        unsigned msel = masks[0];
+#pragma unroll
+        for (int w = 0; w < NW - 1; w++) {   // walk to the wave that holds entry e (branch-free: at most NW - 1 steps)
+            const int cnt = __builtin_popcount(masks[w]);
+            const bool next = wsel == w && e >= cnt;
+            e = next ? e - cnt : e;
+            msel = next ? masks[w + 1] : msel;
+            wsel = next ? w + 1 : wsel;
+        }
+        const int row = qb * (NW * kQPerWave) + wsel * kQPerWave + select_bit(msel, e);
+        // (wave-uniform bounds of the group's rows: its first entry is its lowest row, its last valid entry the highest)
+        const int row_lo = __builtin_amdgcn_readfirstlane(row);
+        const int row_hi = __builtin_amdgcn_readlane(row, min(nrows - g0, kQPerWave) - 1);
         const bool qvalid = row < p.Sq;
         auto qfrag = [&](int s_) -> v8i {
             if (Q16) {
@@ -968,8 +1083,8 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
             *reinterpret_cast<v4i*>(qslot + (s_ << 11)) = v4i{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<v4i*>(qslot + (s_ << 11) + 512) = v4i{f[4], f[5], f[6], f[7]};
         }
-        rescue_rows<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, nullptr,
-                                                                    [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, Q16 ? vx : nullptr);
+        rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
+                                                                       [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, Q16 ? vx : nullptr);
     }
 }
 
@@ -977,7 +1092,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
 // many peaked rows loops back into the same two-term code.
 // Returns the bit mask of the block's 32-row groups (waves) that still need rescue_pass (0: none; CHECK launches only).
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16, bool CHECK>
-__device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char* smem, int bid, int tid) {   // tid: an opaque copy of threadIdx.x
+__device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char* smem, int bid, int tid, volatile unsigned* mail) {   // tid: an opaque copy of threadIdx.x; mail: draw_next_block
     int head, qb;
     map_block(p, bid, p.nqb, CAUSAL, head, qb);
     // Fused step (the original bf16 V is at hand): a block whose first row sees fewer than two_term_keys keys -- early causal rows, short
@@ -989,7 +1104,8 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
             const int nkeys0 = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;
             if (nkeys0 < p.two_term_keys) {   // workgroup-uniform
                 asm volatile("" : "+v"(tid));
-                pv16_block_pass<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL, false, true>(p, smem, tid, bid);
+                pv16_block_pass<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL, false, true>(
+                    p, smem, tid, bid, [&]() { return draw_issue(p, mail, tid); }, [&](unsigned ticket) { draw_finish(p, mail, tid, ticket); });
                 return 0u;
             }
         }
@@ -1009,8 +1125,11 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
             if (!(var >= kVarDeadband)) var = 1.0f;
         }
         const int nkeys = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;   // keys the block's first row attends
-        const float z = var >= kVarDeadband ? fmaxf(p.peak_z, kPeakZWide) : p.peak_z;
-        two = __builtin_amdgcn_readfirstlane(predicted_r((float)nkeys, var, z) < kPeakR0 ? 1 : 0) != 0;   // (every lane holds the same value)
+        // unit variance (or no estimate): the key-count rule; a head that IS wide: two-term when so many rows are expected to end peaked
+        // that gathering and recomputing them would cost more than the two-term sweep
+        const bool wide = var >= kVarDeadband;
+        const bool start_two = predicted_r((float)nkeys, 1.0f, p.peak_z) < kPeakR0 || (wide && many_rows_peaked((float)nkeys, var));
+        two = __builtin_amdgcn_readfirstlane(start_two ? 1 : 0) != 0;   // (every lane holds the same value)
     }
 #ifdef QATTN_DEV
     const unsigned long long dbg_entry = (p.dbg & 16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1029,10 +1148,11 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
     for (;;) {
         asm volatile("" : "+v"(tid));
         if (two) {
-            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, bid, false);
+            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, bid, false, mail);
             break;
         }
-        const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK>(p, smem, tid, bid, CHECK);
+        const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK>(p, smem, tid, bid, CHECK, mail);
+        mail = nullptr;   // (a repeated block has drawn its successor already)
         if (r == 0) break;
         if (r != kPassRedo) {   // a few peaked groups (every wave is past the vote barrier, hence done with the K/V ring)
             to_rescue = (unsigned)r;
@@ -1082,6 +1202,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     // kept live across the block loop costs a vector register the tightest instantiations do not have (one spilled dword).
     const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int bid = blockIdx.x;
+    int parity = 0;   // the mailbox alternates between two words: a wave still reading this block's successor cannot meet the next draw
 #ifdef QATTN_DEV
     int dbg_round = 0;
 #endif
@@ -1090,7 +1211,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
         tid |= wave_s << 6;
         asm volatile("" : "+v"(tid));
-        unsigned resc;
+        int resc;
 #ifdef QATTN_DEV
         // work log (QATTN_V2_DBG=24): per workgroup, per round {block, start, after the block, after its rescues, after the draw}
         unsigned long long* wlog = nullptr;
@@ -1103,7 +1224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
 #endif
         {
             QATTN_PARAMS();
-            resc = run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p, smem, bid, tid);
+            resc = run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p, smem, bid, tid, dynamic ? bcast + parity : nullptr);
         }
 #ifdef QATTN_DEV
         if (wlog && threadIdx.x == 0) wlog[2] = __builtin_amdgcn_s_memrealtime();
@@ -1112,7 +1233,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
             // a few peaked 32-row groups: on the spot, while the head's K / V are in this XCD's L2 (every wave is past the vote
             // barrier, hence done with the K/V ring).  The next block is drawn afterwards: a block reserved before the rescue would
             // wait for it while other workgroups idle (+16 us at the end of a C3 launch).
-            if (resc != 0u) {
+            if (resc != 0) {
                 QATTN_PARAMS();
                 asm volatile("" : "+v"(tid));
                 rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16>(p, smem, tid, bid, resc);
@@ -1124,13 +1245,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
         QATTN_PARAMS();
         int next = -1;
         if (dynamic) {
-            // (the atomic's latency hides behind the other waves' epilogues: wave 0 is one of the first to finish)
-            if (tid == 0) {
-                const int nq = p.sched_nq;
-                bcast[0] = (unsigned)sched_next_block(p.sched, nq, (int)blockIdx.x & (nq - 1), p.total_blocks / nq, (int)gridDim.x / nq);
-            }
+            // the successor was drawn in this block's prologue (draw_next_block)
             lds_barrier();   // also: every wave has left the ring and the Q slots before the next block fills them
-            next = __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast));
+            next = __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
+            parity ^= 1;
         } else if (!CAUSAL && bid + (int)gridDim.x < p.total_blocks) {
             next = bid + (int)gridDim.x;
             lds_barrier();
@@ -1164,7 +1282,7 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     } else {
         p.sched = nullptr;
     }
-    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes
+    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes + the Q prefetch's dump slot
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
 #endif
@@ -1206,7 +1324,7 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     if ((p.dbg & 0xffff) >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
         // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
         const int grid = p.B * p.Hq * p.nqb;
-        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords;
+        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;
         p.n_two = 0; p.peak_r0 = 0.0f; p.total_blocks = grid;
 #define QATTN_ABL_CASE(M)                                                                                          \
         case M: {                                                                                                  \

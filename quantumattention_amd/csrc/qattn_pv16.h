@@ -70,8 +70,9 @@ __device__ __forceinline__ Vec pv16_read_vt(const unsigned char* lo, const unsig
 
 // One 256-row query block.  TOKEN: per-row q scales / per-key k scales (standalone entry only); Q16: the fused step's bf16 Q rows,
 // quantised here with the pre-pass's quant8 sequence (the same q8 bytes as every other pass of the kernel).
-template <int D, int NW, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool Q16>
-__device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid) {
+template <int D, int NW, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool Q16, typename DrawIssue, typename DrawFinish>
+__device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, DrawIssue&& draw_issue_hook,
+                                                DrawFinish&& draw_finish_hook) {   // hooks around the row stores: the D = 128 kernel requests its next block there
     static_assert(D == 128 && NW == 8, "the swizzle and the DMA split are written for 256-byte V rows and 8 waves");
     typedef Pv16Type<V16_FMT> T;
     typedef typename T::vec vec16;
@@ -153,7 +154,6 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
         c = TOKEN ? p.sm_log2e * (qvalid ? p.sq[bh * p.Sq + qrow] : 1.0f) : p.sm_log2e * p.sq[bh] * p.sk[kv_head];
     }
     const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
-
     // ---- per-lane pieces of the transposed-read addresses (T10): lane 4 q4 + p4 of a 16-lane group supplies row R + q4, the 8 bytes
     // at element 4 p4 of the group's 16 columns; the group's columns are d = 32 m + 16 cg .. + 15 (cg = group & 1), its rows start at
     // R = 32 tt + 16 s + 4 hh (elements 0..3 of the operand) and R + 8 (elements 4..7) -- the key order in which the S^T accumulator
@@ -255,7 +255,9 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     }
     auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const unsigned ticket = draw_issue_hook();
     store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_tot, bh * p.Sq + qrow, hh, qvalid);
+    draw_finish_hook(ticket);
     if (p.lse && hh == 0 && qvalid) p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c) + __logf(l_tot)) * p.lse_mul;
 }
 
