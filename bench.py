@@ -340,9 +340,17 @@ def run_rank(args):
         L = _native.lib()
         fp8_dtype = _native.FP8_DTYPE[args.fp8]
 
-        def event_time(fn, n):
-            for _ in range(5):
-                fn()
+        def event_time(fn, n, settle=0.25):
+            # every measurement below follows host-side work during which the GPU fell back to its idle clock (~100 MHz): the same
+            # settle protocol as the headline (--settle) -- untimed calls for `settle` seconds -- before the timed ones; with five
+            # warm-up calls only (rounds 1-3) the causal / wide-q / reference-grid figures included the clock ramp (C3: 0.50 vs 0.45 ms)
+            t_end = time.perf_counter() + settle
+            while True:
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                if time.perf_counter() >= t_end:
+                    break
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()

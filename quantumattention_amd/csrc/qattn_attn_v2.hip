@@ -514,7 +514,8 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         advance();
         QATTN2_STAMP(0);
-        prep_scores<CAUSAL, TOKEN, RAGGED>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
+        // (RAGGED = false, head-wise: the chunk lies inside the key range AND below the wave's causal diagonal -- nothing to prepare)
+        if constexpr (RAGGED || TOKEN) prep_scores<CAUSAL, TOKEN, RAGGED>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
         // (VS) iteration t + 1 multiplies V(t - 1): its scale byte is requested during iteration t (t = 1 runs on the initial 2^0: P = 0)
         full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF>(st, kbuf, vprev, kbuf + CH, qbuf, stage, vx_next);
@@ -522,7 +523,12 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    using Inner = std::integral_constant<bool, CAUSAL>;   // an iteration whose chunk t - 1 is not the head's last one (causal: no static knowledge kept)
+    // An iteration of the main loop exponentiates a chunk <= n_w - 2.  Non-causal: not the head's last chunk, hence inside the key range.
+    // Causal: the wave's rows start at q0 = 32 j and n_w = (q0 + 31) / 64 + 1, so chunk n_w - 2 ends at key 64 (n_w - 1) - 1 <= q0 - 1 for
+    // even j and <= q0 - 33 for odd j: at or below the diagonal of every row of the wave -- only the wave's LAST chunk meets the mask
+    // (and the ragged tail), and that one runs in the copies with the test.  Round 3 kept the run-time test in the causal loop: 345
+    // instead of 276 instructions per two iterations, 5.1 scalar instructions per MFMA at C3 (VERDICT r3 Weak-5).
+    using Inner = std::integral_constant<bool, false>;
     using Last = std::integral_constant<bool, true>;
 #ifdef QATTN_DEV
     for (int i = 0; i < 6; i++) st.seg[i] = 0;
@@ -960,12 +966,18 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     };
     // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
     constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
+    // MEASURED AND LEFT OFF (round 4, QATTN_QPREFETCH = 0; profiles/r04/ab_c2_q_prefetch_variants.log: fused step auto +0.3 %, fast 0 %; separate
+    // call auto +0.3 %, fast -1.7 %; non-temporal form +0.5 %: 64 KiB of once-read bf16 rows per block and CU compete with the two live heads'
+    // K / V for the XCD's 4 MiB L2).  What it does when built in:
     // Static non-causal launches know their next block (bid + grid): near the end of the sweep every wave asks for ITS 32 rows of that
     // block's Q -- 8 KiB of bf16 (fused step) or 4 KiB of fp8, read exactly once and therefore never in a cache -- by LDS-DMA into a 1 KiB
     // dump slot behind the V scale words.  Nothing reads the slot; the point is that the rows then sit in this XCD's L2 when the next
     // block's prologue asks for them in earnest: that request is the longest wait of a block's prologue (dev timeline: prologue 2.9 us
     // of a 65 us block) and no register survives the block boundary for it (round 3's register prefetch: +25 registers, spills).
-    constexpr int NPF = (!CAUSAL && !TWO && BYTE && !TOKEN && NW == 8 && ABL == 0) ? (Q16 ? 8 : 4) : 0;
+#ifndef QATTN_QPREFETCH
+#define QATTN_QPREFETCH 0   // (a build knob for tools/ab.py variants: 0 = off, 1 = default cache policy, 2 = non-temporal)
+#endif
+    constexpr int NPF = (QATTN_QPREFETCH != 0 && !CAUSAL && !TWO && BYTE && !TOKEN && NW == 8 && ABL == 0) ? (Q16 ? 8 : 4) : 0;
     auto prefetch_next = [&]() -> bool {
         if constexpr (NPF == 0) return false;
         else {
@@ -981,7 +993,8 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
             for (int j = 0; j < NPF; j++) {
                 const int r = min(qb2 * QWG + wave * kQPerWave + j * RPP + lane / (RB / 16), p.Sq - 1);
                 const unsigned char* src = qsrc + ((long)head2 * p.Sq + r) * RB + (lane % (RB / 16)) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dump, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dump, 16, 0,
+                                                 QATTN_QPREFETCH == 2 ? 2 : 0);
             }
             return true;
         }

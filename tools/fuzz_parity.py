@@ -72,6 +72,18 @@ for case in range(N):
         if not (np.isfinite(got16).all() and mx16 < tol16):
             fails += 1
             print(f"FAIL #{case:3d} 16-bit attn_func: {mx16:.4f} (tol {tol16:.4f})", flush=True)
+    # the 16-bit-V mode of the fp8 entry (csrc/qattn_pv16.h: the reference kernel's own P.V numerics), D = 128: fp64 SDPA of the same
+    # quantised q, k with the ORIGINAL 16-bit V; P carries 8 (bf16) / 11 (fp16) mantissa bits: 2^-7 max(1, |O|, std V)
+    mxv = tolv = 0.0
+    if D == 128 and case % 2 == 1:
+        refv = oracle.attention_forward(q8, k8, bits16(v), FMT[fp8], FMT[fp8], fmt16(dtype), sq, sk, None, scale_mode=m, causal=causal)
+        gotv = out_to_f32(_native.fp8_attention_forward(qg8, kf, vc, sqg, skg, None, Hkv=Hkv, Skv=Skv, out_dtype=dtype, is_causal=causal,
+                                                        scaling=scaling))
+        mxv, _ = err_stats(gotv, refv)
+        tolv = 2.0 ** -7 * max(1.0, float(np.abs(refv).max()), float(v.float().std()))
+        if not (np.isfinite(gotv).all() and mxv < tolv):
+            fails += 1
+            print(f"FAIL #{case:3d} 16-bit-V mode: {mxv:.4f} (tol {tolv:.4f})", flush=True)
     # quantiser: bit-exact payloads and scales
     q_ok = np.array_equal(bits8(qg8), q8) and np.array_equal(sqg.cpu().numpy(), sq) and \
         np.array_equal(unpack_frag(bits8(kf), _native.LAYOUT_KFRAG, B, Hkv, Skv, D)[:, :, :Skv], k8) and np.array_equal(skg.cpu().numpy(), sk)
@@ -87,7 +99,7 @@ for case in range(N):
     worst[key] = max(worst.get(key, 0.0), mx_f / tol, mx_s / tol) if graded else worst.get(key, 0.0)
     print(f"{'ok  ' if ok else 'FAIL'} #{case:3d} B{B} Hq{Hq} Hkv{Hkv} Sq{Sq} Skv{Skv} D{D} {'causal' if causal else 'full  '} {fp8} {scaling[:5]} "
           f"{'bf16' if dtype == torch.bfloat16 else 'fp16'} {precision:8s} q x{spread}: quant {'exact' if q_ok else 'DIFFERS'} | fused {mx_f:.4f} sep {mx_s:.4f} (tol {tol:.4f})"
-          f"{'' if finite else ' NON-FINITE'}{f' | 16-bit {mx16:.4f} (tol {tol16:.4f})' if tol16 else ''}", flush=True)
+          f"{'' if finite else ' NON-FINITE'}{f' | 16-bit {mx16:.4f} (tol {tol16:.4f})' if tol16 else ''}{f' | 16-bit-V {mxv:.4f} (tol {tolv:.4f})' if tolv else ''}", flush=True)
 print(f"{N} cases, {fails} failures, {time.time() - t0:.0f} s; worst error / tolerance per (D, scaling, precision):")
 for key in sorted(worst):
     print("  ", key, f"{worst[key]:.2f}")
