@@ -196,6 +196,13 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
 
 
 #define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+// (build knob for tools/ab.py variants, two-term passes only: 1 = the softmax groups of two neighbouring slots are scheduled together --
+//  eight independent scores per dependent chain of exp / convert / decode / subtract / convert instead of four; 2 = no fence inside the iteration)
+#ifndef QATTN_TWO_MERGE
+#define QATTN_TWO_MERGE 0
+#endif
+#define QATTN_SLOT_FENCE_PAIR() do { if constexpr (!(TWO && QATTN_TWO_MERGE >= 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QATTN_SLOT_FENCE_ODD() do { if constexpr (!(TWO && QATTN_TWO_MERGE >= 2)) __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifndef QATTN_DEV
 #define QATTN2_STAMP(I) do { } while (0)
 #else
@@ -265,7 +272,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     mxa = max3_raw(mxa, sc0[9], sc0[10]);
     mxb = max3_raw(mxb, sc0[11], sc0[12]);
     mxc = max3_raw(mxc, sc0[13], sc0[14]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_ODD();
     // slot 1: O1 += V1.P(t-2)            reads: V3            VALU: max over tile 1, group 0
     st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], pp, st.o[1], st.vsx);
     if (TWO) st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], ppl, st.o[1], st.vsx);
@@ -281,7 +288,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     mxc = max3_raw(mxc, sc1[15], sc1[15]);
     float mx = max3_raw(mxa, mxb, mxc);
     QATTN_SM_GROUP(true, sc0, 0, mc, 0, pp[0]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_PAIR();
     // slot 2: O2 += V2.P(t-2)            reads: Q k-step 0, K(tile 0, k-step 0)      VALU: group 1
     st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, pp, st.o[2], st.vsx);
     if (TWO) st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, ppl, st.o[2], st.vsx);
@@ -289,13 +296,13 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     if (QREG) qf = st.qreg[0]; else qf = LDSF(qbuf);
     v8i ka = LDSF(kbuf + (0 << 11));
     QATTN_SM_GROUP(false, sc0, 1, mc, 1, pc[0]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_ODD();
     // slot 3: O3 += V3.P(t-2)            reads: K(tile 1, k-step 0)                  VALU: group 2
     st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, pp, st.o[3], st.vsx);
     if (TWO) st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, ppl, st.o[3], st.vsx);
     v8i kb = LDSF(kbuf + (2 << 11));
     QATTN_SM_GROUP(false, sc0, 2, mc, 2, pc[1]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_PAIR();
     QATTN2_STAMP(1);
     stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
@@ -306,14 +313,14 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     if (QREG) qg = st.qreg[1]; else qg = LDSF(qbuf + (1 << 11));
     v8i kc = LDSF(kbuf + (1 << 11));   // K(tile 0, k-step 1)
     QATTN_SM_GROUP(false, sc0, 3, mc, 3, pc[2]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_ODD();
     // slot 5: S0 = K(0,0).Q0             reads: K(tile 1, k-step 1)                  VALU: group 4
 #pragma unroll
     for (int r = 0; r < 16; r++) { sn0[r] = 0.0f; sn1[r] = 0.0f; }
     sn0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf, sn0);
     v8i kd = LDSF(kbuf + (3 << 11));
     QATTN_SM_GROUP(false, sc1, 0, mc, 4, pc[3]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_PAIR();
     // slot 6: S1 = K(1,0).Q0             reads: next iteration's V0                  VALU: group 5
     sn1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf, sn1);
     st.vpre[0] = LDSF(vnext + (0 << 11));
@@ -321,12 +328,12 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     // at the top of its own iteration it put a whole LDS round trip in front of the first MFMA of every iteration
     if (VS) st.vsx = (int)*vx_next;
     QATTN_SM_GROUP(false, sc1, 1, mc, 5, pc[4]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_ODD();
     // slot 7: S0 += K(0,1).Q1            reads: next iteration's V1                  VALU: group 6
     sn0 = mfma_f8<QK_FMT, QK_FMT>(kc, qg, sn0);
     st.vpre[1] = LDSF(vnext + (1 << 11));
     QATTN_SM_GROUP(false, sc1, 2, mc, 6, pc[5]);
-    QATTN_SLOT_FENCE();
+    QATTN_SLOT_FENCE_PAIR();
     // slot 8: S1 += K(1,1).Q1                                                        VALU: group 7, max exchange
     sn1 = mfma_f8<QK_FMT, QK_FMT>(kd, qg, sn1);
     QATTN_SM_GROUP(false, sc1, 3, mc, 7, pc[6]);
