@@ -602,10 +602,10 @@ __device__ __forceinline__ void rescue_rows_at(const AttnParams& p, unsigned cha
             for (int i = 0; i < 4; i++) { e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[4 * j + i], c, mc)); ls += e[i]; }
             int hi = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], 0);
             hi = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2], e[3], hi);
-            const float h0 = __builtin_amdgcn_cvt_f32_fp8(hi, 0), h1 = __builtin_amdgcn_cvt_f32_fp8(hi, 1);
-            const float h2 = __builtin_amdgcn_cvt_f32_fp8(hi, 2), h3 = __builtin_amdgcn_cvt_f32_fp8(hi, 3);
-            int lo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h0, e[1] - h1, 0);
-            lo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h2, e[3] - h3, lo);
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 h01 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), h23 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+            int lo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h01[0], e[1] - h01[1], 0);
+            lo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h23[0], e[3] - h23[1], lo);
             ph[w] = hi; pl[w] = lo;
         }
         l_run += ls;

@@ -130,24 +130,31 @@ __device__ __forceinline__ void pv_chunk(const unsigned char* vbuf, const v8i& p
 // 4 scores -> 4 exponentials -> one dword of the e4m3 P operand (+ the residual dword when TWO); accumulates the
 // partial row sums in acc[0..3] (FIRST: initialises them).  `seed` only provides the register the first
 // v_cvt_pk_fp8_f32 writes its low half into (its high half is overwritten by the second), saving a v_mov.
-template <bool TWO, bool FIRST, bool NEFF = false>
+// ACC = false (two-term passes of the kernels without an LSE output): no fp32 row sum here -- the sums of the QUANTISED terms come
+// from the matrix pipe (full_step, SUMM), 36 vector instructions per chunk less in a pass that is bound by vector issue.
+template <bool TWO, bool FIRST, bool NEFF = false, bool ACC = true>
 __device__ __forceinline__ void exp_group(const v16f& sx, int j, float c, float mc, float (&acc)[4], v8i& pv, v8i& plv,
                                           int w, int seed, float* acc2 = nullptr) {
     float e[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[4 * j + i], c, mc));
-        acc[i] = FIRST ? e[i] : acc[i] + e[i];
+        if (ACC) acc[i] = FIRST ? e[i] : acc[i] + e[i];
         if (NEFF) acc2[i] = FIRST ? e[i] * e[i] : __builtin_fmaf(e[i], e[i], acc2[i]);
     }
-    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));  // sums stay in this slot
-    int ph = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], seed);
+    if (ACC) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));  // sums stay in this slot
+    // (v_cvt_pk_fp8_f32 keeps the other half of its destination: handed a LIVE register as that destination -- the seed the one-term
+    //  callers pass is dead where they pass it, the two-term pass's is not -- the compiler copies it first; an undefined register costs nothing)
+    int fresh_hi, fresh_lo;
+    asm volatile("" : "=v"(fresh_hi), "=v"(fresh_lo));
+    int ph = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0], e[1], TWO ? fresh_hi : seed);
     ph = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2], e[3], ph);
     if (TWO) {
-        const float h0 = __builtin_amdgcn_cvt_f32_fp8(ph, 0), h1 = __builtin_amdgcn_cvt_f32_fp8(ph, 1);
-        const float h2 = __builtin_amdgcn_cvt_f32_fp8(ph, 2), h3 = __builtin_amdgcn_cvt_f32_fp8(ph, 3);
-        int plo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h0, e[1] - h1, ph);
-        plo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h2, e[3] - h3, plo);
+        // (v_cvt_pk_f32_fp8: two bytes per instruction -- the pass is bound by vector issue)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 h01 = __builtin_amdgcn_cvt_pk_f32_fp8(ph, false), h23 = __builtin_amdgcn_cvt_pk_f32_fp8(ph, true);
+        int plo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h01[0], e[1] - h01[1], fresh_lo);
+        plo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h23[0], e[3] - h23[1], plo);
         asm volatile("" : "+v"(plo));
         plv[w] = plo;
     }
@@ -196,13 +203,6 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
 
 
 #define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
-// (build knob for tools/ab.py variants, two-term passes only: 1 = the softmax groups of two neighbouring slots are scheduled together --
-//  eight independent scores per dependent chain of exp / convert / decode / subtract / convert instead of four; 2 = no fence inside the iteration)
-#ifndef QATTN_TWO_MERGE
-#define QATTN_TWO_MERGE 0
-#endif
-#define QATTN_SLOT_FENCE_PAIR() do { if constexpr (!(TWO && QATTN_TWO_MERGE >= 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
-#define QATTN_SLOT_FENCE_ODD() do { if constexpr (!(TWO && QATTN_TWO_MERGE >= 2)) __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifndef QATTN_DEV
 #define QATTN2_STAMP(I) do { } while (0)
 #else
@@ -223,7 +223,7 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
         if (ABL & 4) break;                                                         \
         if (BYTE && (ABL & 32)) byte_group_u8(SX, J, cx, MC, pc, W, SEED);           \
         else if (BYTE) byte_group<false>(SX, J, cx, MC, pc, W, SEED);                \
-        else exp_group<TWO, FIRST, NEFF>(SX, J, cx, MC, acc, pc, pcl, W, SEED, acc2); \
+        else exp_group<TWO, FIRST, NEFF, !SUMM>(SX, J, cx, MC, acc, pc, pcl, W, SEED, acc2); \
     } while (0)
 
 // One pipelined iteration (1 <= t <= n_w): PV(t-2), [row-sum MFMA], QK(t), softmax(t-1) in hand-placed MFMA slots.
@@ -235,7 +235,7 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
 // bandwidth, are the scarce resource at two waves per SIMD).
 //   kbuf  : stage(t),   K part  (+ lane offset)      vprev : stage(t-1), V part = V(t-2)
 //   vnext : stage(t),   V part = V(t-1) (prefetch for the next iteration)
-template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, typename Stage>
+template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, bool SUMM = false, typename Stage>
 __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const unsigned char* kbuf, const unsigned char* vprev,
                                           const unsigned char* vnext, const unsigned char* qbuf, Stage&& stage, const unsigned* vx_next = nullptr) {
     static_assert(D == 128, "hand-placed slots are written for D = 128");
@@ -272,7 +272,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     mxa = max3_raw(mxa, sc0[9], sc0[10]);
     mxb = max3_raw(mxb, sc0[11], sc0[12]);
     mxc = max3_raw(mxc, sc0[13], sc0[14]);
-    QATTN_SLOT_FENCE_ODD();
+    QATTN_SLOT_FENCE();
     // slot 1: O1 += V1.P(t-2)            reads: V3            VALU: max over tile 1, group 0
     st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], pp, st.o[1], st.vsx);
     if (TWO) st.o[1] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(st.vpre[1], ppl, st.o[1], st.vsx);
@@ -288,7 +288,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     mxc = max3_raw(mxc, sc1[15], sc1[15]);
     float mx = max3_raw(mxa, mxb, mxc);
     QATTN_SM_GROUP(true, sc0, 0, mc, 0, pp[0]);
-    QATTN_SLOT_FENCE_PAIR();
+    QATTN_SLOT_FENCE();
     // slot 2: O2 += V2.P(t-2)            reads: Q k-step 0, K(tile 0, k-step 0)      VALU: group 1
     st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, pp, st.o[2], st.vsx);
     if (TWO) st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, ppl, st.o[2], st.vsx);
@@ -296,31 +296,32 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     if (QREG) qf = st.qreg[0]; else qf = LDSF(qbuf);
     v8i ka = LDSF(kbuf + (0 << 11));
     QATTN_SM_GROUP(false, sc0, 1, mc, 1, pc[0]);
-    QATTN_SLOT_FENCE_ODD();
+    QATTN_SLOT_FENCE();
     // slot 3: O3 += V3.P(t-2)            reads: K(tile 1, k-step 0)                  VALU: group 2
     st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, pp, st.o[3], st.vsx);
     if (TWO) st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, ppl, st.o[3], st.vsx);
     v8i kb = LDSF(kbuf + (2 << 11));
     QATTN_SM_GROUP(false, sc0, 2, mc, 2, pc[1]);
-    QATTN_SLOT_FENCE_PAIR();
+    QATTN_SLOT_FENCE();
     QATTN2_STAMP(1);
     stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
-    if (BYTE) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+    if (BYTE || SUMM) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+    if (SUMM && TWO) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, ppl, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
     // ... and of its bytes read as e5m2 ~= P'^2 / 2 (WaveState::lsq)
     if (BYTE && NEFF) st.lsq = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsq, QATTN_FMT_E4M3, QATTN_FMT_E5M2, 0, 0, 0, 0);
     v8i qg;                            // Q k-step 1
     if (QREG) qg = st.qreg[1]; else qg = LDSF(qbuf + (1 << 11));
     v8i kc = LDSF(kbuf + (1 << 11));   // K(tile 0, k-step 1)
     QATTN_SM_GROUP(false, sc0, 3, mc, 3, pc[2]);
-    QATTN_SLOT_FENCE_ODD();
+    QATTN_SLOT_FENCE();
     // slot 5: S0 = K(0,0).Q0             reads: K(tile 1, k-step 1)                  VALU: group 4
 #pragma unroll
     for (int r = 0; r < 16; r++) { sn0[r] = 0.0f; sn1[r] = 0.0f; }
     sn0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf, sn0);
     v8i kd = LDSF(kbuf + (3 << 11));
     QATTN_SM_GROUP(false, sc1, 0, mc, 4, pc[3]);
-    QATTN_SLOT_FENCE_PAIR();
+    QATTN_SLOT_FENCE();
     // slot 6: S1 = K(1,0).Q0             reads: next iteration's V0                  VALU: group 5
     sn1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf, sn1);
     st.vpre[0] = LDSF(vnext + (0 << 11));
@@ -328,12 +329,12 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     // at the top of its own iteration it put a whole LDS round trip in front of the first MFMA of every iteration
     if (VS) st.vsx = (int)*vx_next;
     QATTN_SM_GROUP(false, sc1, 1, mc, 5, pc[4]);
-    QATTN_SLOT_FENCE_ODD();
+    QATTN_SLOT_FENCE();
     // slot 7: S0 += K(0,1).Q1            reads: next iteration's V1                  VALU: group 6
     sn0 = mfma_f8<QK_FMT, QK_FMT>(kc, qg, sn0);
     st.vpre[1] = LDSF(vnext + (1 << 11));
     QATTN_SM_GROUP(false, sc1, 2, mc, 6, pc[5]);
-    QATTN_SLOT_FENCE_PAIR();
+    QATTN_SLOT_FENCE();
     // slot 8: S1 += K(1,1).Q1                                                        VALU: group 7, max exchange
     sn1 = mfma_f8<QK_FMT, QK_FMT>(kd, qg, sn1);
     QATTN_SM_GROUP(false, sc1, 3, mc, 7, pc[6]);
@@ -344,7 +345,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
         if (!TWO) st.m_true = max3_raw(st.m_true, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
         mx = max3_raw(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
     }
-    float ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float ls = (BYTE || SUMM) ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     float ls2 = (BYTE || !NEFF) ? 0.0f : (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]);
     QATTN_SLOT_FENCE();
     QATTN2_STAMP(2);
@@ -359,7 +360,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
             for (int r = 0; r < 16; r++) st.o[m][r] *= alpha;
         st.l_run *= alpha;
         if (NEFF) st.l2_run *= alpha * alpha;
-        if (BYTE) {
+        if (BYTE || SUMM) {
             // lane n < 16 holds the sums of queries n (its own alpha) and n + 16 (lane n+16's alpha)
             const float alpha16 = __uint_as_float(swizzle_xor16(__float_as_uint(alpha)));   // (lanes 0..15 get lanes 16..31, no lane-index register)
             st.lsum[0] *= alpha;
@@ -375,7 +376,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
         for (int j = 1; j < 4; j++) QATTN_SM_GROUP(false, sc0, j, mc2, j, 0);
 #pragma unroll
         for (int j = 0; j < 4; j++) QATTN_SM_GROUP(false, sc1, j, mc2, 4 + j, 0);
-        ls = BYTE ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        ls = (BYTE || SUMM) ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
         ls2 = (BYTE || !NEFF) ? 0.0f : (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]);
     }
     st.l_run += ls;
@@ -409,7 +410,7 @@ __device__ __forceinline__ void stage_dma8(const unsigned char* kg, const unsign
 // block's Q rows -- NPF LDS-DMA pieces per wave into a dump slot nobody reads, which leaves the rows in this XCD's L2 -- and says
 // whether it did; the sweep's remaining waits then leave those NPF youngest requests in flight (s_waitcnt vmcnt(NPF): the counter is in
 // order and no K/V stage is requested after this point of a non-causal sweep).
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, int NPF = 0, typename LoadQ, typename Prefetch>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, int NPF = 0, bool SUMM = false, typename LoadQ, typename Prefetch>
 __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q,
@@ -525,7 +526,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         if constexpr (RAGGED || TOKEN) prep_scores<CAUSAL, TOKEN, RAGGED>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
         // (VS) iteration t + 1 multiplies V(t - 1): its scale byte is requested during iteration t (t = 1 runs on the initial 2^0: P = 0)
-        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF>(st, kbuf, vprev, kbuf + CH, qbuf, stage, vx_next);
+        full_step<D, QK_FMT, V_FMT, PAR, TWO, BYTE, ABL, QREG, VS, NEFF, SUMM>(st, kbuf, vprev, kbuf + CH, qbuf, stage, vx_next);
         if constexpr (VS) vx_next = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(vx_next) + vx_step);
     };
     using P0 = std::integral_constant<int, 0>;
@@ -541,7 +542,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     for (int i = 0; i < 6; i++) st.seg[i] = 0;
     st.tlast = __builtin_amdgcn_s_memtime();
 #endif
-    if (BYTE) {
+    if (BYTE || SUMM) {
         {   // A of the row-sum MFMA: lane = row (l & 15) + 16 * k-group; rows 0 / 1 are 1.0 (e4m3 0x38) on even / odd k-groups
             const int row = lane & 15, kg = lane >> 4;
             const int one = ((row == 0 && !(kg & 1)) || (row == 1 && (kg & 1))) ? 0x38383838 : 0;
@@ -654,7 +655,8 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
                 st.o[2] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fc, ppl, st.o[2], st.vsx);
                 st.o[3] = mfma_pv<V_FMT, QATTN_FMT_E4M3, VS>(fd, ppl, st.o[3], st.vsx);
             }
-            if (BYTE) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+            if (BYTE || SUMM) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
+            if (SUMM && TWO) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, ppl, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
             if (BYTE && NEFF) st.lsq = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsq, QATTN_FMT_E4M3, QATTN_FMT_E5M2, 0, 0, 0, 0);
         };
         if (t & 1) tail(P1{}); else tail(P0{});
@@ -690,7 +692,7 @@ __device__ __forceinline__ void draw_finish(const AttnParams& p, volatile unsign
 // caller repeats the block in two-term mode -- or the bit mask of the (at most max_rescue) waves whose 32-row groups
 // rescue_pass then recomputes; the other waves' rows (and the optional LSE) are stored.  0: everything is stored.
 constexpr int kPassRedo = 1 << 30;
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, bool NEFF = false, int NPF = 0, typename LoadQ, typename Prefetch>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, bool NEFF = false, int NPF = 0, bool SUMM = false, typename LoadQ, typename Prefetch>
 __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
                                              int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q,
@@ -734,7 +736,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
         }
     };
-    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF, NPF>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
+    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF, NPF, SUMM>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
                                                                                      !TWO && check_peaked, vote, vx, first_stages_issued, prefetch))
     {   // forecast: the block is peaked, nothing was stored (its successor is drawn here: the repeated pass draws nothing)
         const int t_ = (wave << 6) | lane;
@@ -772,7 +774,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
 
     // ---- combine the two half-wave partial sums
     float l_tot, l2_tot = 0.0f;   // l2_tot: sum of P'^2 (exact mode) or kNeffByteRatio of it (BYTE)
-    if (BYTE) {
+    if (BYTE || SUMM) {
         // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
         const float s0 = bcast_low16(st.lsum[0]), s1 = bcast_low16(st.lsum[1]);
         l_tot = (lane & 16) ? s1 : s0;
@@ -855,7 +857,13 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
 
 // Everything a wave derives from its thread / block index for one pass over its query rows, and that pass itself (the Q^T
 // fragments are re-loaded by a second pass: a few KiB against the pass's megabytes of K / V).
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16, bool NEFF = false>
+// SUMM (MEASURED AND NOT USED, round 4: every instantiation passes false): the row sums of the QUANTISED hi and lo terms from the matrix
+// pipe -- two v_mfma_f32_16x16x128 per chunk on the operands the PV products consume (full_step) -- instead of 36 fp32 additions per chunk
+// and lane.  The two-term sweep is bound by vector-instruction issue, and this took 4.8 % off it (profiles/r04/ab_two_term_valu_diet.log) --
+// but it breaks the bound on very peaked rows (q x 3 at S = 4096: 0.022): thousands of keys 15 binades below the row's top key flush to
+// zero in fp8; their V rows average out of the numerator, but their weights ARE 0.5 .. 1 % of the denominator, and a denominator that
+// drops them too rescales the output by that much.  The exact fp32 sum of the un-rounded exponentials stays.
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16, bool NEFF = false, bool SUMM = false>
 __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked, volatile unsigned* mail = nullptr) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
@@ -1006,7 +1014,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
             return true;
         }
     };
-    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO && !(ABL & 512), NPF>(   // (ABL 512: dev timing of the statistic's cost)
+    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO && !(ABL & 512), NPF, SUMM && TWO && !BYTE>(   // (ABL 512: dev timing of the statistic's cost)
         p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst, mail, prefetch_next);
 }
 
@@ -1168,7 +1176,8 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
     for (;;) {
         asm volatile("" : "+v"(tid));
         if (two) {
-            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16>(p, smem, tid, bid, false, mail);
+            // (SUMM = false: see block_pass)
+            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16, false, false>(p, smem, tid, bid, false, mail);
             break;
         }
         const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK>(p, smem, tid, bid, CHECK, mail);

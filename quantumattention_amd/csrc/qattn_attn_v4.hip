@@ -212,7 +212,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
                     sx[4 * j + 0] *= w.x; sx[4 * j + 1] *= w.y; sx[4 * j + 2] *= w.z; sx[4 * j + 3] *= w.w;
                 }
         }
-        const bool need_mask = (k0 + 64 > p.Skv) || (CAUSAL && k0 + 63 > q0);
+        const bool need_mask = (k0 + 64 > p.Skv) || (CAUSAL && k0 + 63 > q0);   // (a single compare `t == n_w - 1` measured no faster: D = 64 +-0, D = 256 +1.7 %)
         if (__builtin_expect(need_mask, 0)) {
 #pragma unroll
             for (int r = 0; r < 32; r++) {
@@ -295,10 +295,10 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
                 pv[w] = ph;
                 int plo = 0;
                 if (two) {
-                    const float h0 = __builtin_amdgcn_cvt_f32_fp8(ph, 0), h1 = __builtin_amdgcn_cvt_f32_fp8(ph, 1);
-                    const float h2 = __builtin_amdgcn_cvt_f32_fp8(ph, 2), h3 = __builtin_amdgcn_cvt_f32_fp8(ph, 3);
-                    plo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h0, e[1] - h1, 0);
-                    plo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h2, e[3] - h3, plo);
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 h01 = __builtin_amdgcn_cvt_pk_f32_fp8(ph, false), h23 = __builtin_amdgcn_cvt_pk_f32_fp8(ph, true);
+                    plo = cvt_pk_fp8<QATTN_FMT_E4M3, false>(e[0] - h01[0], e[1] - h01[1], 0);
+                    plo = cvt_pk_fp8<QATTN_FMT_E4M3, true>(e[2] - h23[0], e[3] - h23[1], plo);
                 }
                 pl[w] = plo;
             }
