@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define QATTN_ABI_VERSION 5
+#define QATTN_ABI_VERSION 6   /* 6 (round 4): v_fmt = QATTN_FMT_BF16 / _FP16 in qattn_fp8_attention_forward, qattn_mfma_probe */
 
 /* element formats */
 #define QATTN_FMT_E4M3 0 /* OCP float8_e4m3fn  (torch.float8_e4m3fn) */
@@ -143,7 +143,11 @@ int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S
  * FP8 fused attention forward:  O = softmax(sm_scale * (sq*Q8)(sk*K8)^T [+causal mask]) (sv*V8),  flash-style.
  *   q8        [B,Hq,Sq,D]   fp8 (qk_fmt), row-major
  *   k8        [B,Hkv,Skv,D] fp8 (qk_fmt), QATTN_LAYOUT_KFRAG
- *   v8        [B,Hkv,Skv,D] fp8 (v_fmt),  QATTN_LAYOUT_VFRAG
+ *   v8        [B,Hkv,Skv,D] fp8 (v_fmt = qk_fmt), QATTN_LAYOUT_VFRAG -- both GEMMs on FP8 MFMA;
+ *             or (v_fmt = QATTN_FMT_BF16 / QATTN_FMT_FP16 = out_fmt, D = 128) the ORIGINAL 16-bit value tensor, dense ROW-MAJOR, no scale_v:
+ *             every row then runs the reference kernel's own P.V numerics -- FP8 QK^T, 16-bit P, 16-bit V (tk/attention.py:72,286,318) --
+ *             on v_mfma_f32_32x32x16_{bf16,f16} (csrc/qattn_pv16.h; about 1.5x the time; `precision` plays no part: P carries 8 / 11
+ *             mantissa bits).  Other head dims: QATTN_ERR_UNSUPPORTED_FMT.
  *   out       [B,Hq,Sq,D]   bf16 or fp16 (out_fmt), row-major, written in full
  *   lse       NULL, or fp32 log-sum-exp of the scaled scores per query row in `lse_layout` (B*Hq rows of
  *             qattn_lse_row_stride(Sq, lse_layout) floats) -- the per-row vector the reference defines but disables
@@ -157,7 +161,7 @@ int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S
  *             graph-capture safe) and one word per 32-row query group.  Needed for QATTN_PRECISION_AUTO; may be NULL otherwise,
  *             a causal launch then uses one workgroup per query block and a large non-causal one equal static shares (a few
  *             per cent slower on long sequences; the same results bit for bit).  Nothing in it outlives the call.
- * Both GEMMs run on v_mfma_f32_32x32x64_f8f6f4; accumulation, running max/sum and the softmax are fp32.
+ * Both GEMMs run on v_mfma_f32_32x32x64_f8f6f4 (fp8 V); accumulation, running max/sum and the softmax are fp32.
  */
 size_t qattn_attention_workspace_bytes(int B, int Hq, int Sq);
 size_t qattn_lse_row_stride(int Sq, int lse_layout);
@@ -173,7 +177,9 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
  * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
- * and one write of Q.  There, and with head-wise scales at D = 64 / 256 (both for Skv <= 16384), V is also quantised
+ * and one write of Q.  There the query blocks (256 rows) whose first row sees fewer than 1024 keys -- early causal rows, every row of
+ * a short sequence -- attend the ORIGINAL 16-bit V with 16-bit P (the reference's numerics, as v_fmt = 16-bit above) instead of
+ * the quantised V.  There, and with head-wise scales at D = 64 / 256 (both for Skv <= 16384), V is also quantised
  * differently from qattn_quant_qkv_fp8: one power-of-two scale per 64-key chunk, found inside the quantise pass (no abs-max pass over V) and applied by the kernel's PV products as
  * the MFMA's E8M0 block scale; v8 then holds those payloads, scale_v is written as 1.0 and the chunk scales live in the
  * workspace (oracle restatement: oracle.quantize_v_block).  Everywhere else results are bit-identical to the separate

@@ -13,7 +13,7 @@ FMT_E4M3, FMT_E5M2, FMT_BF16, FMT_FP16 = 0, 1, 2, 3
 SCALE_HEAD, SCALE_TOKEN = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_KFRAG, LAYOUT_VFRAG, LAYOUT_K16FRAG, LAYOUT_V16FRAG = 0, 1, 2, 3, 4
 NUMERICS = {"compiled": 0, "eager": 1}
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRECISION = {"auto": 0, "fast": 1, "accurate": 2}
 LSE_NATURAL, LSE_REFERENCE = 0, 1
 

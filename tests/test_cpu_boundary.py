@@ -28,7 +28,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert getattr(L, n) is not None, n
     lib = _native.lib()
-    assert lib.qattn_abi_version() == _native.ABI_VERSION == 5
+    assert lib.qattn_abi_version() == _native.ABI_VERSION == 6
 
 
 def test_abi_size_queries_and_error_codes_need_no_gpu():
