@@ -177,9 +177,10 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
  * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
- * and one write of Q.  There the query blocks (256 rows) whose first row sees fewer than 1024 keys -- early causal rows, every row of
- * a short sequence -- attend the ORIGINAL 16-bit V with 16-bit P (the reference's numerics, as v_fmt = 16-bit above) instead of
- * the quantised V.  There, and with head-wise scales at D = 64 / 256 (both for Skv <= 16384), V is also quantised
+ * and one write of Q.  At D = 128 (any 16-bit input format, head- or token-wise scales) the query blocks (256 rows) whose first row sees fewer
+ * than 1024 keys -- early causal rows, every row of a short sequence -- attend the ORIGINAL 16-bit V with 16-bit P (the reference's
+ * numerics, as v_fmt = 16-bit above) instead of the quantised V: inside the fused kernel for bf16 head-wise inputs, by a launch of
+ * their own otherwise; on those rows the step's results are NOT those of the separate calls (which only have the fp8 V).  There, and with head-wise scales at D = 64 / 256 (both for Skv <= 16384), V is also quantised
  * differently from qattn_quant_qkv_fp8: one power-of-two scale per 64-key chunk, found inside the quantise pass (no abs-max pass over V) and applied by the kernel's PV products as
  * the MFMA's E8M0 block scale; v8 then holds those payloads, scale_v is written as 1.0 and the chunk scales live in the
  * workspace (oracle restatement: oracle.quantize_v_block).  Everywhere else results are bit-identical to the separate

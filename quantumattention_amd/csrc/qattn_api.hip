@@ -184,8 +184,18 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.peak_z = (float)p.two_term_keys > kPeakR0 ? 0.5f + logf((float)p.two_term_keys / kPeakR0) : 0.0f;   // see predicted_r
     const bool prof = ds != nullptr;
     if (prof) (void)hipEventRecord(ds->prof[0], st);
-    int rc;
-    if (v_is_16) rc = launch_attn_pv16(p, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
+    int rc = QATTN_OK;
+    if (!v_is_16 && use_v2 && p.v16 != nullptr && p.q16 == nullptr && p.lse == nullptr) {
+        // fused step on the D = 128 kernel WITHOUT in-kernel Q quantisation (fp16 inputs): its early rows through a 16-bit-V launch of
+        // their own, the main launch skips those blocks (the bf16 fused step has the pass inside its kernel)
+        const int n_early = pv16_early_blocks(a.Sq, a.Skv, a.is_causal, p.two_term_keys);
+        if (n_early > 0) {
+            rc = launch_attn_pv16(p, a.qk_fmt, a.out_fmt, a.is_causal, a.scale_mode, st, n_early);
+            p.skip_early = 1;
+        }
+    }
+    if (rc != QATTN_OK) { /* fall through to the error return below */ }
+    else if (v_is_16) rc = launch_attn_pv16(p, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
     else if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     else rc = launch_attn_v4_full(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     if (prof) { (void)hipEventRecord(ds->prof[1], st); ds->recorded = true; }
@@ -464,7 +474,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, fuse_q ? v : nullptr, stamps, zero_in_prepass};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, D == 128 ? v : nullptr, stamps, zero_in_prepass};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

@@ -132,6 +132,7 @@ struct AttnParams {
     // The ORIGINAL 16-bit V, row-major [B,Hkv,Skv,D] (else nullptr): what pv16_block_pass (qattn_pv16.h) attends -- every block of a
     // call with v_fmt = QATTN_FMT_BF16 / _FP16, and in the fused step the blocks that see fewer than two_term_keys keys (bf16)
     const unsigned char* v16;
+    int skip_early;                // D = 128 kernel: the blocks that see fewer than two_term_keys keys were attended by a 16-bit-V launch of their own (launch_attn_pv16): nothing to do for them here
     const unsigned char* q16;      // fused step: the 16-bit (bf16) Q tensor, quantised row by row in the kernel prologue (else nullptr)
     const unsigned* q_amax_part;   // fused step: abs-max words (fp32 bits) of every q head, [B*Hq][amax_stride], amax_n valid per head:
     int amax_n, amax_stride;       //   the abs-max pass's per-block words, or ONE caller-supplied word per head (producer hand-off)

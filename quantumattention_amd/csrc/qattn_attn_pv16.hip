@@ -27,7 +27,9 @@ static int launch_fmt(const AttnParams& p, int causal, int scale_mode, hipStream
     return tok ? launch_one<QK_FMT, V16_FMT, false, true>(p, st) : launch_one<QK_FMT, V16_FMT, false, false>(p, st);
 }
 
-int launch_attn_pv16(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st) {
+int launch_attn_pv16(const AttnParams& pin, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks) {
+    AttnParams p = pin;
+    if (n_blocks > 0) { p.nqb = n_blocks < p.nqb ? n_blocks : p.nqb; p.risky_lo = p.risky_hi = 0; }   // (the grid and map_block follow nqb)
     if (qk_fmt == QATTN_FMT_E4M3)
         return v16_fmt == QATTN_FMT_BF16 ? launch_fmt<QATTN_FMT_E4M3, QATTN_FMT_BF16>(p, causal, scale_mode, st)
                                          : launch_fmt<QATTN_FMT_E4M3, QATTN_FMT_FP16>(p, causal, scale_mode, st);

@@ -1127,6 +1127,13 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
     // sequences -- runs the reference kernel's own P.V numerics, 16-bit P on the un-quantised V (qattn_pv16.h), instead of two-term fp8
     // P on the fp8 V: row 0 of a causal head IS V[0], and an fp8 V puts its rounding error (up to 2^-4 relative) straight into the output.
     // The same MFMA time as the two-term pass (16 bf16 products of 32 cycles for 8 fp8 products of 64), fewer VALU instructions.
+    if (p.skip_early) {   // (those blocks ran in a 16-bit-V launch of their own: fp16 inputs, launch_attn_pv16 in qattn_api.hip)
+        const int nkeys0 = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;
+        if (nkeys0 < p.two_term_keys) {
+            draw_finish(p, mail, tid, draw_issue(p, mail, tid));
+            return 0u;
+        }
+    }
     if constexpr (Q16 && NW == 8) {
         if (p.v16 != nullptr) {
             const int nkeys0 = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;

@@ -263,6 +263,17 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
 
 // The 16-bit-V form of qattn_fp8_attention_forward (v_fmt = QATTN_FMT_BF16 / _FP16): every query block through pv16_block_pass, one
 // workgroup per block (map_block: XCD-contiguous heads, causal blocks heaviest first).
-int launch_attn_pv16(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st);
+// n_blocks > 0: only the first n_blocks query blocks of every head (the fused step's early rows on the paths whose main kernel has no
+// 16-bit-V pass of its own: token-wise scales, fp16 inputs).
+int launch_attn_pv16(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks = 0);
+// leading query blocks (of 256 rows) whose first row sees fewer than two_term_keys keys
+inline int pv16_early_blocks(int Sq, int Skv, int causal, int two_term_keys) {
+    // block qb sees Skv keys (non-causal) or min(Skv, 256 qb + 1): early while that is below the threshold
+    const int nqb = ceil_div(Sq, kQPerWG);
+    if (Skv < two_term_keys) return nqb;
+    if (!causal) return 0;
+    const int cnt = (two_term_keys - 1 + kQPerWG - 1) / kQPerWG;
+    return cnt < nqb ? cnt : nqb;
+}
 
 }  // namespace qattn

@@ -52,32 +52,35 @@ def fused_step_uses_block_v(D, scaling, dtype, Skv) -> bool:
 
 
 def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfloat16, scaling="head", causal=False,
-                        sm_scale=0.0, return_lse=False, v_block=False, q_offset=0, v16_early=None):
+                        sm_scale=0.0, return_lse=False, v_block=False, q_offset=0, v16_early=None, fused=False):
     """O3 of SURVEY.md §8c: fp64 SDPA on the same quantised q, k AND the build's quantised v (v_block: the fused step's
-    block-scaled V, oracle.quantize_v_block; else one scale per head).  v16_early (default: on for D = 128 with v_block): the rows
-    the fused step runs through its 16-bit-V pass are graded against fp64 SDPA with the original 16-bit V."""
+    block-scaled V, oracle.quantize_v_block; else one scale per head).  fused (implied by v_block): the call under test is the fused
+    step, whose early rows at D = 128 attend the original 16-bit V (v16_early overrides the rule either way)."""
+    fused = fused or v_block
     if v_block:
         _, _, vdq = oracle.quantize_v_block(v16b, fmt16(v_dtype), FMT[fp8])
         res = oracle.attention_forward(q8b, k8b, vdq, FMT[fp8], FMT[fp8], oracle.FMT_BF16, sq, sk, None, scale_mode=scaling,
                                        causal=causal, sm_scale=sm_scale, return_lse=return_lse, q_offset=q_offset)
-        # The fused step at D = 128 (bf16, head-wise: the only D = 128 case with a block-scaled V) attends the ORIGINAL 16-bit V in the
-        # query blocks (256 rows) whose first row sees fewer than 1024 keys -- the reference kernel's own P.V numerics, qattn_pv16.h:
-        # causal, the leading blocks; non-causal, every block when Skv < 1024.
-        Sq, D, Skv = np.asarray(q8b).shape[2], np.asarray(q8b).shape[3], np.asarray(k8b).shape[2]
-        if (D == 128 and v16_early is None) or v16_early:
-            first_row = ((np.arange(Sq) + q_offset) // 256) * 256
-            early = (np.minimum(Skv, first_row + 1) if causal else np.full(Sq, Skv)) < 1024
-            n_early = int(early.sum())
-            if n_early:
-                assert early[:n_early].all()   # a prefix of the rows
-                r16 = oracle.attention_forward(np.asarray(q8b)[:, :, :n_early], k8b, v16b, FMT[fp8], FMT[fp8], fmt16(v_dtype), sq, sk, None,
-                                               scale_mode=scaling, causal=causal, sm_scale=sm_scale, return_lse=False, q_offset=q_offset)
-                out = res[0] if return_lse else res
-                out[:, :, :n_early] = r16
-        return res
-    v8, sv = oracle.quantize_fp8(v16b, fmt16(v_dtype), "head", FMT[fp8], "compiled")
-    return oracle.attention_forward(q8b, k8b, v8, FMT[fp8], FMT[fp8], FMT[fp8], sq, sk, sv, scale_mode=scaling,
-                                    causal=causal, sm_scale=sm_scale, return_lse=return_lse, q_offset=q_offset)
+    else:
+        v8, sv = oracle.quantize_fp8(v16b, fmt16(v_dtype), "head", FMT[fp8], "compiled")
+        res = oracle.attention_forward(q8b, k8b, v8, FMT[fp8], FMT[fp8], FMT[fp8], sq, sk, sv, scale_mode=scaling,
+                                       causal=causal, sm_scale=sm_scale, return_lse=return_lse, q_offset=q_offset)
+    # The fused step at D = 128 (any 16-bit dtype, head- or token-wise scales) attends the ORIGINAL 16-bit V in the query blocks (256 rows)
+    # whose first row sees fewer than 1024 keys -- the reference kernel's own P.V numerics, csrc/qattn_pv16.h: causal, the leading
+    # blocks; every block when Skv < 1024.  (bf16 head-wise: a pass inside the fused kernel; token-wise / fp16: a launch of its own.)
+    Sq, D, Skv = np.asarray(q8b).shape[2], np.asarray(q8b).shape[3], np.asarray(k8b).shape[2]
+    if (D == 128 and v16_early is None and fused) or v16_early:
+        first_row = ((np.arange(Sq) + q_offset) // 256) * 256
+        early = (np.minimum(Skv, first_row + 1) if causal else np.full(Sq, Skv)) < 1024
+        n_early = int(early.sum())
+        if n_early:
+            assert early[:n_early].all()   # a prefix of the rows
+            sq_e = np.asarray(sq)[:, :, :n_early] if np.asarray(sq).ndim == 3 else sq      # token-wise: one q scale per row
+            r16 = oracle.attention_forward(np.asarray(q8b)[:, :, :n_early], k8b, v16b, FMT[fp8], FMT[fp8], fmt16(v_dtype), sq_e, sk, None,
+                                           scale_mode=scaling, causal=causal, sm_scale=sm_scale, return_lse=False, q_offset=q_offset)
+            out = res[0] if return_lse else res
+            out[:, :, :n_early] = r16
+    return res
 
 
 def err_stats(got: np.ndarray, ref: np.ndarray):

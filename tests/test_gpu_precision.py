@@ -80,7 +80,7 @@ def test_dominant_exact_top_key_over_a_crushed_rest(S, D, scaling, mult):
     m = "head" if scaling == "head-wise" else "token"
     q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, m, oracle.FMT_E4M3)
     k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, m, oracle.FMT_E4M3)
-    ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, scaling=m, v_block=fused_step_uses_block_v(D, scaling, q.dtype, S))
+    ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, scaling=m, v_block=fused_step_uses_block_v(D, scaling, q.dtype, S), fused=True)
     fn = qa.fp8_attn_func if scaling == "head-wise" else qa.fp8_token_wise_attn_func
     with qa.config.patch({"attention.precision": "auto"}):
         auto = out_to_f32(fn(q.cuda(), k.cuda(), v.cuda()))

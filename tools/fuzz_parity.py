@@ -49,8 +49,8 @@ for case in range(N):
     q8, sq = oracle.quantize_fp8(bits16(q), fmt16(dtype), m, FMT[fp8])
     k8, sk = oracle.quantize_fp8(bits16(k), fmt16(dtype), m, FMT[fp8])
     vb = fused_step_uses_block_v(D, scaling, dtype, Skv)
-    ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal, v_block=vb)
-    ref_sep = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal) if vb else ref
+    ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal, v_block=vb, fused=True)
+    ref_sep = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal) if (vb or D == 128) else ref   # (the separate calls: fp8 V with one scale per head, on every row)
     qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
     with qa.config.patch({"attention.precision": precision, "attention.fp8_format": fp8}):
         fn = qa.fp8_attn_func if scaling == "head-wise" else qa.fp8_token_wise_attn_func
