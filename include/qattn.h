@@ -144,7 +144,7 @@ int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S
  *   q8        [B,Hq,Sq,D]   fp8 (qk_fmt), row-major
  *   k8        [B,Hkv,Skv,D] fp8 (qk_fmt), QATTN_LAYOUT_KFRAG
  *   v8        [B,Hkv,Skv,D] fp8 (v_fmt = qk_fmt), QATTN_LAYOUT_VFRAG -- both GEMMs on FP8 MFMA;
- *             or (v_fmt = QATTN_FMT_BF16 / QATTN_FMT_FP16 = out_fmt, D = 128) the ORIGINAL 16-bit value tensor, dense ROW-MAJOR, no scale_v:
+ *             or (v_fmt = QATTN_FMT_BF16 / QATTN_FMT_FP16 = out_fmt) the ORIGINAL 16-bit value tensor, dense ROW-MAJOR, no scale_v:
  *             every row then runs the reference kernel's own P.V numerics -- FP8 QK^T, 16-bit P, 16-bit V (tk/attention.py:72,286,318) --
  *             on v_mfma_f32_32x32x16_{bf16,f16} (csrc/qattn_pv16.h; about 1.5x the time; `precision` plays no part: P carries 8 / 11
  *             mantissa bits).  Other head dims: QATTN_ERR_UNSUPPORTED_FMT.
@@ -177,7 +177,7 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
  * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
- * and one write of Q.  At D = 128 (any 16-bit input format, head- or token-wise scales) the query blocks (256 rows) whose first row sees fewer
+ * and one write of Q.  For every head dim, 16-bit input format and scale mode the query blocks (256 rows) whose first row sees fewer
  * than 1024 keys -- early causal rows, every row of a short sequence -- attend the ORIGINAL 16-bit V with 16-bit P (the reference's
  * numerics, as v_fmt = 16-bit above) instead of the quantised V: inside the fused kernel for bf16 head-wise inputs, by a launch of
  * their own otherwise; on those rows the step's results are NOT those of the separate calls (which only have the fp8 V).  There, and with head-wise scales at D = 64 / 256 (both for Skv <= 16384), V is also quantised

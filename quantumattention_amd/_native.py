@@ -251,7 +251,7 @@ def fp8_attention_forward(q8: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.
                           lse_layout: int = LSE_NATURAL):
     """q8: row-major fp8 [B,Hq,Sq,D]; k_frag / v_frag: fragment-layout buffers for [B,Hkv,Skv,D].
     v_frag may instead be the ORIGINAL 16-bit value tensor, row-major bf16 / fp16 [B,Hkv,Skv,D] (scale_v = None): the call then runs
-    the reference kernel's own P.V numerics -- 16-bit P on the un-quantised V (tk/attention.py:72,286,318) -- for every row (D = 128).
+    the reference kernel's own P.V numerics -- 16-bit P on the un-quantised V (tk/attention.py:72,286,318) -- for every row.
     return_lse: also the log-sum-exp rows; LSE_REFERENCE gives the reference-defined strided view (include/qattn.h)."""
     _require(q8.is_cuda and q8.dim() == 4, "fp8_attention_forward needs a 4-D device query")
     q8 = q8.contiguous()

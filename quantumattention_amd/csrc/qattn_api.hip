@@ -99,10 +99,10 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     if (a.Hq % a.Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;                      // tk/attention.py:398-399
     if (a.qk_fmt != QATTN_FMT_E4M3 && a.qk_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
     // v_fmt: the fp8 format of q / k (both GEMMs on FP8 MFMA, the main path), or a 16-bit format: v8 is then the caller's ROW-MAJOR
-    // 16-bit V and every row runs the reference's own P.V numerics (qattn_pv16.h); D = 128, no two-term / AUTO machinery involved
+    // 16-bit V and every row runs the reference's own P.V numerics (qattn_pv16.h); no two-term / AUTO machinery involved
     const bool v_is_16 = a.v_fmt == QATTN_FMT_BF16 || a.v_fmt == QATTN_FMT_FP16;
     if (!v_is_16 && a.v_fmt != a.qk_fmt) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (v_is_16 && (a.D != 128 || a.q16 != nullptr || a.out_fmt != a.v_fmt)) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (v_is_16 && (a.q16 != nullptr || a.out_fmt != a.v_fmt)) return QATTN_ERR_UNSUPPORTED_FMT;
     if (a.out_fmt != QATTN_FMT_BF16 && a.out_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
     if (a.scale_mode != QATTN_SCALE_HEAD && a.scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
     if (a.precision != QATTN_PRECISION_AUTO && a.precision != QATTN_PRECISION_FAST && a.precision != QATTN_PRECISION_ACCURATE) return QATTN_ERR_INVALID_ARG;
@@ -190,12 +190,12 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
         // their own, the main launch skips those blocks (the bf16 fused step has the pass inside its kernel)
         const int n_early = pv16_early_blocks(a.Sq, a.Skv, a.is_causal, p.two_term_keys);
         if (n_early > 0) {
-            rc = launch_attn_pv16(p, a.qk_fmt, a.out_fmt, a.is_causal, a.scale_mode, st, n_early);
+            rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.out_fmt, a.is_causal, a.scale_mode, st, n_early);
             p.skip_early = 1;
         }
     }
     if (rc != QATTN_OK) { /* fall through to the error return below */ }
-    else if (v_is_16) rc = launch_attn_pv16(p, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
+    else if (v_is_16) rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
     else if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     else rc = launch_attn_v4_full(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     if (prof) { (void)hipEventRecord(ds->prof[1], st); ds->recorded = true; }
@@ -474,7 +474,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, D == 128 ? v : nullptr, stamps, zero_in_prepass};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, v, stamps, zero_in_prepass};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

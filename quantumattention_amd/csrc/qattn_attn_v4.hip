@@ -478,12 +478,12 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
     if (rows_two < p.Sq)
         rc = byte_exp ? launch_v4_d<D, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
                       : launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
-    // the fused step at D = 128 (token-wise scales here): the query blocks that see fewer than two_term_keys keys attend the ORIGINAL
+    // the fused step (D = 64 / 256, and D = 128 with token-wise scales): the query blocks that see fewer than two_term_keys keys attend the ORIGINAL
     // 16-bit V with 16-bit P (qattn_pv16.h) instead of two-term fp8 P on the fp8 V; the rest of rows_two (ACCURATE) stays two-term
     int rows_early = 0;
-    if (D == 128 && p.v16 != nullptr && p.lse == nullptr) {
+    if (p.v16 != nullptr && p.lse == nullptr) {
         rows_early = min(rows_two, pv16_early_blocks(p.Sq, p.Skv, causal, p.two_term_keys) * 256);
-        if (rc == QATTN_OK && rows_early > 0) rc = launch_attn_pv16(p, fmt, p.out_fmt, causal, scale_mode, st, rows_early / 256);
+        if (rc == QATTN_OK && rows_early > 0) rc = launch_attn_pv16(p, D, fmt, p.out_fmt, causal, scale_mode, st, rows_early / 256);
     }
     if (rc == QATTN_OK && rows_two > rows_early) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_early, rows_two, 1, st);
     // flagged 32-row groups: rescued one by one where a 256-row block has few of them, else the block is redone

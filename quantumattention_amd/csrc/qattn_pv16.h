@@ -73,14 +73,24 @@ __device__ __forceinline__ Vec pv16_read_vt(const unsigned char* lo, const unsig
 template <int D, int NW, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool Q16, typename DrawIssue, typename DrawFinish>
 __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, DrawIssue&& draw_issue_hook,
                                                 DrawFinish&& draw_finish_hook) {   // hooks around the row stores: the D = 128 kernel requests its next block there
-    static_assert(D == 128 && NW == 8, "the swizzle and the DMA split are written for 256-byte V rows and 8 waves");
+    static_assert((D == 64 || D == 128 || D == 256) && NW == 8, "the DMA split is written for 8 waves");
+    static_assert(!Q16 || D == 128, "the fused in-kernel form belongs to the D = 128 kernel");
     typedef Pv16Type<V16_FMT> T;
     typedef typename T::vec vec16;
     constexpr int CH = 64 * D;          // fp8 K chunk
-    constexpr int VCH = 64 * D * 2;     // 16-bit V chunk
+    constexpr int RB = 2 * D;           // bytes of a 16-bit V row
+    constexpr int VCH = 64 * RB;        // 16-bit V chunk
     constexpr int STAGE = CH + VCH;
     constexpr int KS = D / 64, MB = D / 32;
-    static_assert(kPv16Slots * STAGE <= (2 * 2 + 1) * 2 * CH, "the ring fits the fp8 sweeps' K/V ring");
+    constexpr int KP = CH / 1024, VPW = 2 * KP / NW;   // 1 KiB pieces of a K chunk (4 / 8 / 16); V pieces per wave (1 / 2 / 4)
+    constexpr int CPR = RB / 16, RPP = 1024 / RB;      // 16-byte chunks per V row (8 / 16 / 32); rows per piece (8 / 4 / 2)
+    static_assert(D != 128 || kPv16Slots * STAGE <= (2 * 2 + 1) * 2 * CH, "D = 128: the ring fits the fp8 sweeps' K/V ring");
+    static_assert(kPv16Slots * STAGE <= 160 * 1024, "the ring fits a CU's LDS");
+    // The XOR that spreads the transposed reads over the banks, on the 16-byte chunk index of V row r (see the file header for D = 128).
+    // A 32-lane half reads 4 rows (r & 3 = 0..3) x 64 bytes; a 64-byte granule covers 16 of the 64 banks, so the four rows' granules must
+    // differ mod 4.  Rows are RB bytes apart: D = 128 / 256 (256 / 512 B, = 0 mod 256): XOR the granule index (chunk bits 2..3) with
+    // r & 3; D = 64 (128 B: rows r and r + 2 collide): XOR chunk bit 2 with bit 1 of r.
+    auto swz = [](int r) -> int { return D == 128 ? (((r & 3) << 2) | ((r >> 2) & 3)) : D == 256 ? ((r & 3) << 2) : (((r >> 1) & 1) << 2); };
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
@@ -100,23 +110,37 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + QWG, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
 
-    // ---- one ring stage by LDS-DMA: K chunk t (one 1 KiB piece per wave) and V rows 64 t .. 64 t + 63 (two 4-row pieces per wave)
-    const int vr = lane >> 4;                                  // row of the piece this lane copies a chunk of
+    // ---- one ring stage by LDS-DMA: K chunk t (KP pieces of 1 KiB over the waves) and V rows 64 t .. 64 t + 63 (VPW pieces of RPP rows per wave)
+    const int vr = lane / CPR, vc = lane % CPR;                // row within a piece / 16-byte chunk within the row this lane copies
     auto dma_stage = [&](int t, int slot) {
         unsigned char* dst = smem + slot * STAGE;
-        const unsigned char* ksrc = kg + (long)min(t, p.nchunks - 1) * CH + (wave << 10) + (lane << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
-                                         (__attribute__((address_space(3))) void*)(dst + (wave << 10)), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int pc = wave * 2 + i;
-            const int r = 4 * pc + vr;
+        for (int r = 0; r < (KP + NW - 1) / NW; r++) {
+            const int pc = wave + NW * r;                       // (D = 64: waves 0 .. 3 only)
+            if (pc < KP) {
+                const unsigned char* ksrc = kg + (long)min(t, p.nchunks - 1) * CH + (pc << 10) + (lane << 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
+                                                 (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPW; i++) {
+            const int pc = wave * VPW + i;
+            const int r = RPP * pc + vr;
             const int key = min(t * 64 + r, p.Skv - 1);
-            const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
-            const unsigned char* vsrc = vg + (long)key * (D * 2) + (ch << 4);
+            const int ch = vc ^ swz(r);
+            const unsigned char* vsrc = vg + (long)key * RB + (ch << 4);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
                                              (__attribute__((address_space(3))) void*)(dst + CH + (pc << 10)), 16, 0, 0);
         }
+    };
+    // this wave's pieces per stage: the s_waitcnt immediate that leaves exactly the NEXT stage in flight
+    auto wait_stage = [&](bool next_in_flight) {
+        if (!next_in_flight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if constexpr (D == 64) {
+            if (wave < KP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else if constexpr (D == 128) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     };
     if (n_wg > 0) dma_stage(0, 0);
     if (n_wg > 1) dma_stage(1, 1);
@@ -160,8 +184,10 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     // registers 8 s .. 8 s + 7 become a B operand.  R & 3 = 0 and (R >> 2) & 3 = hh resp. hh + 2, so f(row) = (q4 << 2) | hh [+ 2].
     const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
     const int cc = 2 * cg + (p4 >> 1);
-    const unsigned tr_lo = 256u * (4 * hh + q4) + 16u * (cc ^ hh) + 8u * (p4 & 1);
-    const unsigned tr_hi = 256u * (4 * hh + 8 + q4) + 16u * (cc ^ (hh + 2)) + 8u * (p4 & 1);
+    // (D = 128: the low chunk bits take (R >> 2) & 3 = hh resp. hh + 2; the other images leave them alone)
+    const unsigned tr_lo = (unsigned)RB * (4 * hh + q4) + 16u * (cc ^ (D == 128 ? hh : 0)) + 8u * (p4 & 1);
+    const unsigned tr_hi = (unsigned)RB * (4 * hh + 8 + q4) + 16u * (cc ^ (D == 128 ? hh + 2 : 0)) + 8u * (p4 & 1);
+    const int qsw = D == 64 ? (q4 >> 1) : q4;                   // what the granule index m is XOR-ed with (swz above, on rows R + q4)
     const int frag_lane_off = (hh << 10) + (ql << 4);
 
     v16f o[MB];
@@ -175,8 +201,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     for (int t = 0; t < n_wg; t++) {
         // stage t has landed (this wave's three pieces; the stage behind it may still be in flight), then everyone's pieces are visible
         // and every wave has left the slot that stage t + 2 is about to overwrite
-        if (t + 1 < n_wg) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_stage(t + 1 < n_wg);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 2 < n_wg) dma_stage(t + 2, slot >= 1 ? slot - 1 : slot + 2);
@@ -192,7 +217,25 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
                 s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf[s], s0);
                 s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf[s], s1);
             }
-            prep_scores<CAUSAL, TOKEN>(s0, s1, p, t * 64, q0, qrow, hh, skt);
+            if constexpr (TOKEN) {
+                // per-key scales: registers 4 j .. 4 j + 3 of tile tt hold keys t 64 + 32 tt + 8 j + 4 hh .. + 3.  The 8 scales of (tt, j) sit at
+                // a wave-uniform address -- scalar loads, the lane's half picked by hh -- so they cost no vector registers (at D = 256 the
+                // pass has none to spare: 128 of O^T, 32 of Q^T, 32 of scores, 16 of P).  Keys beyond Skv: the last scale (masked below).
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int kb = t * 64 + 32 * tt + 8 * j;
+                        const int last = p.Skv - 1;
+                        v16f& sx = tt ? s1 : s0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const float wa = skt[min(kb + i, last)], wb = skt[min(kb + 4 + i, last)];
+                            sx[4 * j + i] *= hh ? wb : wa;
+                        }
+                    }
+            }
+            prep_scores<CAUSAL, false>(s0, s1, p, t * 64, q0, qrow, hh, nullptr);
             float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
@@ -239,14 +282,14 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
             l_run += ls;
 #pragma unroll
             for (int m = 0; m < MB; m++) {
-                const unsigned xm = 64u * (unsigned)(m ^ q4);
+                const unsigned xm = 64u * (unsigned)(m ^ qsw);
                 const unsigned char* alo = vbuf + tr_lo + xm;
                 const unsigned char* ahi = vbuf + tr_hi + xm;
 #pragma unroll
                 for (int tt = 0; tt < 2; tt++)
 #pragma unroll
                     for (int s = 0; s < 2; s++) {
-                        const int roff = 256 * (32 * tt + 16 * s);
+                        const int roff = RB * (32 * tt + 16 * s);
                         o[m] = T::mfma(pv16_read_vt<vec16>(alo + roff, ahi + roff), pb[tt][s], o[m]);
                     }
             }
@@ -265,7 +308,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
 // workgroup per block (map_block: XCD-contiguous heads, causal blocks heaviest first).
 // n_blocks > 0: only the first n_blocks query blocks of every head (the fused step's early rows on the paths whose main kernel has no
 // 16-bit-V pass of its own: token-wise scales, fp16 inputs).
-int launch_attn_pv16(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks = 0);
+int launch_attn_pv16(const AttnParams& p, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks = 0);
 // leading query blocks (of 256 rows) whose first row sees fewer than two_term_keys keys
 inline int pv16_early_blocks(int Sq, int Skv, int causal, int two_term_keys) {
     // block qb sees Skv keys (non-causal) or min(Skv, 256 qb + 1): early while that is below the threshold

@@ -97,7 +97,7 @@ def fp8_attention_forward(
         raise RuntimeError(reason)
     scaling = "head-wise" if scale_q.dim() == 2 else "token-wise"
     k_frag = _native.pack_fp8(key, _native.LAYOUT_KFRAG)
-    if config.attention.pv_precision == "16bit" and D == 128:
+    if config.attention.pv_precision == "16bit":
         # the reference kernel's own numerics: value stays 16-bit, P is cast to 16 bit (tk/attention.py:72,286,318)
         v_frag, scale_v = value, None
     else:

@@ -55,7 +55,7 @@ def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfl
                         sm_scale=0.0, return_lse=False, v_block=False, q_offset=0, v16_early=None, fused=False):
     """O3 of SURVEY.md §8c: fp64 SDPA on the same quantised q, k AND the build's quantised v (v_block: the fused step's
     block-scaled V, oracle.quantize_v_block; else one scale per head).  fused (implied by v_block): the call under test is the fused
-    step, whose early rows at D = 128 attend the original 16-bit V (v16_early overrides the rule either way)."""
+    step, whose early rows attend the original 16-bit V (v16_early overrides the rule either way)."""
     fused = fused or v_block
     if v_block:
         _, _, vdq = oracle.quantize_v_block(v16b, fmt16(v_dtype), FMT[fp8])
@@ -65,11 +65,11 @@ def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfl
         v8, sv = oracle.quantize_fp8(v16b, fmt16(v_dtype), "head", FMT[fp8], "compiled")
         res = oracle.attention_forward(q8b, k8b, v8, FMT[fp8], FMT[fp8], FMT[fp8], sq, sk, sv, scale_mode=scaling,
                                        causal=causal, sm_scale=sm_scale, return_lse=return_lse, q_offset=q_offset)
-    # The fused step at D = 128 (any 16-bit dtype, head- or token-wise scales) attends the ORIGINAL 16-bit V in the query blocks (256 rows)
+    # The fused step (every head dim, any 16-bit dtype, head- or token-wise scales) attends the ORIGINAL 16-bit V in the query blocks (256 rows)
     # whose first row sees fewer than 1024 keys -- the reference kernel's own P.V numerics, csrc/qattn_pv16.h: causal, the leading
-    # blocks; every block when Skv < 1024.  (bf16 head-wise: a pass inside the fused kernel; token-wise / fp16: a launch of its own.)
+    # blocks; every block when Skv < 1024.  (D = 128 bf16 head-wise: a pass inside the fused kernel; elsewhere a launch of its own.)
     Sq, D, Skv = np.asarray(q8b).shape[2], np.asarray(q8b).shape[3], np.asarray(k8b).shape[2]
-    if (D == 128 and v16_early is None and fused) or v16_early:
+    if (v16_early is None and fused) or v16_early:
         first_row = ((np.arange(Sq) + q_offset) // 256) * 256
         early = (np.minimum(Skv, first_row + 1) if causal else np.full(Sq, Skv)) < 1024
         n_early = int(early.sum())

@@ -121,12 +121,10 @@ def test_fused_path_from_16bit_inputs(case):
         mx2, rmse2 = err_stats(out_to_f32(out2), ref)
         assert mx2 < tol_for(ref) and rmse2 < 2e-3 * max(1.0, float(np.abs(ref).max())), (mx2, rmse2)
     else:
-        # the op and the direct C-ABI sequence agree bit for bit -- outside the fused step's early rows at D = 128 (16-bit V there,
+        # the op and the direct C-ABI sequence agree bit for bit -- outside the fused step's early rows (16-bit V there,
         # csrc/qattn_pv16.h; the separate calls have only the fp8 V)
-        n_early = 0
-        if D == 128:
-            first_row = (np.arange(Sq) // 256) * 256
-            n_early = int(((np.minimum(Skv, first_row + 1) if causal else np.full(Sq, Skv)) < 1024).sum())
+        first_row = (np.arange(Sq) // 256) * 256
+        n_early = int(((np.minimum(Skv, first_row + 1) if causal else np.full(Sq, Skv)) < 1024).sum())
         assert torch.equal(out2[:, :, n_early:], out[:, :, n_early:]), "the op and the direct C-ABI sequence must agree bit for bit"
     # asking for the LSE selects the exact-exponential path (the fast path's row sum is of the quantised P)
     out3, lse = _native.fp8_attention_forward(qg8, kf, vf, sqg, skg, svg, Hkv=Hkv, Skv=Skv, out_dtype=dtype,
