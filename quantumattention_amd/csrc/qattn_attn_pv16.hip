@@ -6,20 +6,28 @@
 
 namespace qattn {
 
-// (D = 256: 128 registers of O^T per lane -- one workgroup per CU, which its 144 KiB ring asks for anyway)
-template <int D, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN>
-__global__ __launch_bounds__(kThreads, D == 256 ? 1 : 2) void attn_pv16_kernel(const AttnParams p) {
+// (two waves per SIMD = 256 registers: D = 256 holds 128 of O^T per lane; one workgroup per CU, which its 144 KiB ring asks for anyway)
+// PP: the two-group loop with a four-stage ring (whole-tensor launches at D = 128, qattn_pv16.h); else the one-group loop, three stages
+template <int D, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool PP>
+__global__ __launch_bounds__(kThreads, 2) void attn_pv16_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pv16_block_pass<D, kWaves, QK_FMT, V16_FMT, CAUSAL, TOKEN, false>(p, smem, (int)threadIdx.x, (int)blockIdx.x, []() { return 0u; }, [](unsigned) {});
+    pv16_block_pass<D, kWaves, QK_FMT, V16_FMT, CAUSAL, TOKEN, false, PP ? 4 : 3, PP>(p, smem, (int)threadIdx.x, (int)blockIdx.x, []() { return 0u; }, [](unsigned) {});
 }
 
-template <int D, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN>
-static int launch_one(const AttnParams& p, hipStream_t st) {
-    constexpr int lds = kPv16Slots * (64 * D + 64 * D * 2);
-    auto kern = attn_pv16_kernel<D, QK_FMT, V16_FMT, CAUSAL, TOKEN>;
+template <int D, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool PP>
+static int launch_pp(const AttnParams& p, hipStream_t st) {
+    constexpr int lds = (PP ? 4 : 3) * (64 * D + 64 * D * 2);
+    auto kern = attn_pv16_kernel<D, QK_FMT, V16_FMT, CAUSAL, TOKEN, PP>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.Hq * p.nqb)), dim3(kThreads), lds, st, p);
     return QATTN_OK;
+}
+template <int D, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN>
+static int launch_one(const AttnParams& p, hipStream_t st) {
+    if constexpr (D == 128) {
+        if (p.total_blocks == 0) return launch_pp<D, QK_FMT, V16_FMT, CAUSAL, TOKEN, true>(p, st);   // (launch_attn_pv16: 0 = every block of every head)
+    }
+    return launch_pp<D, QK_FMT, V16_FMT, CAUSAL, TOKEN, false>(p, st);
 }
 
 template <int D, int QK_FMT, int V16_FMT>
@@ -40,7 +48,8 @@ static int launch_d(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, in
 
 int launch_attn_pv16(const AttnParams& pin, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks) {
     AttnParams p = pin;
-    if (n_blocks > 0) { p.nqb = n_blocks < p.nqb ? n_blocks : p.nqb; p.risky_lo = p.risky_hi = 0; }   // (the grid and map_block follow nqb)
+    p.total_blocks = 0;   // (here: "a whole-tensor launch", read by launch_one)
+    if (n_blocks > 0) { p.nqb = n_blocks < p.nqb ? n_blocks : p.nqb; p.risky_lo = p.risky_hi = 0; p.total_blocks = 1; }   // (the grid and map_block follow nqb)
     if (D == 64) return launch_d<64>(p, qk_fmt, v16_fmt, causal, scale_mode, st);
     if (D == 128) return launch_d<128>(p, qk_fmt, v16_fmt, causal, scale_mode, st);
     if (D == 256) return launch_d<256>(p, qk_fmt, v16_fmt, causal, scale_mode, st);

@@ -41,28 +41,51 @@ struct Pv16Type<QATTN_FMT_BF16> {
     typedef pv16_bf16x8 vec;
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack2_bf16(a, b); }
-    static __device__ __forceinline__ float sum2(unsigned w) { return __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u); }   // the two ROUNDED values
+    static __device__ __forceinline__ v4f mfma_sum(vec a, vec b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static constexpr unsigned kOnes = 0x3f803f80u;   // two 1.0
 };
 template <>
 struct Pv16Type<QATTN_FMT_FP16> {
     typedef pv16_f16x8 vec;
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack2_f16(a, b); }
-    static __device__ __forceinline__ float sum2(unsigned w) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        h2 h;
-        __builtin_memcpy(&h, &w, 4);
-        return (float)h[0] + (float)h[1];
-    }
+    static __device__ __forceinline__ v4f mfma_sum(vec a, vec b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static constexpr unsigned kOnes = 0x3c003c00u;
 };
 
 // two transposed reads -> the 8 elements of one A operand (keys R .. R+3 and R+8 .. R+11 of this lane's d column)
+// Issued through asm: behind the builtin (a known LDS load) the compiler waits for EVERY LDS-DMA in flight first -- it cannot tell that the
+// ring slot being read is not the one being filled -- which drained the stage requested a moment earlier at every chunk (s_waitcnt vmcnt(0)
+// in front of the first transposed read).  The ring protocol's own counted wait and barrier are what order these reads; the caller waits
+// for the data with pv16_wait_lds<N> (N = transposed reads issued after the ones it needs).
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2i32 pv16_read_tr(unsigned addr) {
+    v2i32 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ v2i32 pv16_read_tr_at(unsigned addr) {
+    v2i32 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+// the eight reads of one 32-column block of V^T (operands of its four products) are awaited together; the registers are operands of
+// the wait so that no product is scheduled above it
+template <int N>
+__device__ __forceinline__ void pv16_wait_lds(v2i32 (&r)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pv16_wait_lds(v2i32 (&r)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
 template <typename Vec>
-__device__ __forceinline__ Vec pv16_read_vt(const unsigned char* lo, const unsigned char* hi) {
-    const v4s16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)lo);
-    const v4s16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)hi);
-    typedef short v8s16 __attribute__((ext_vector_type(8)));
-    const v8s16 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+__device__ __forceinline__ Vec pv16_operand(v2i32 lo, v2i32 hi) {
+    const v4i r = {lo[0], lo[1], hi[0], hi[1]};
     Vec out;
     __builtin_memcpy(&out, &r, 16);
     return out;
@@ -70,7 +93,7 @@ __device__ __forceinline__ Vec pv16_read_vt(const unsigned char* lo, const unsig
 
 // One 256-row query block.  TOKEN: per-row q scales / per-key k scales (standalone entry only); Q16: the fused step's bf16 Q rows,
 // quantised here with the pre-pass's quant8 sequence (the same q8 bytes as every other pass of the kernel).
-template <int D, int NW, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool Q16, typename DrawIssue, typename DrawFinish>
+template <int D, int NW, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool Q16, int NS = kPv16Slots, bool PP = false, typename DrawIssue, typename DrawFinish>
 __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, DrawIssue&& draw_issue_hook,
                                                 DrawFinish&& draw_finish_hook) {   // hooks around the row stores: the D = 128 kernel requests its next block there
     static_assert((D == 64 || D == 128 || D == 256) && NW == 8, "the DMA split is written for 8 waves");
@@ -84,8 +107,15 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     constexpr int KS = D / 64, MB = D / 32;
     constexpr int KP = CH / 1024, VPW = 2 * KP / NW;   // 1 KiB pieces of a K chunk (4 / 8 / 16); V pieces per wave (1 / 2 / 4)
     constexpr int CPR = RB / 16, RPP = 1024 / RB;      // 16-byte chunks per V row (8 / 16 / 32); rows per piece (8 / 4 / 2)
-    static_assert(D != 128 || kPv16Slots * STAGE <= (2 * 2 + 1) * 2 * CH, "D = 128: the ring fits the fp8 sweeps' K/V ring");
-    static_assert(kPv16Slots * STAGE <= 160 * 1024, "the ring fits a CU's LDS");
+    static_assert(NS >= 3 && NS <= 4, "ring depth: see the two loop forms below");
+    static_assert(NS * STAGE <= 160 * 1024, "the ring fits a CU's LDS");
+    // PP: the two-group loop (below) instead of the one-group loop.  It pays on long sweeps at D = 128 (whole-tensor launches: C2 shape 0.823
+    // against 0.836 ms, S = 16384 2.97 against 3.07) and costs on the short ones of the fused step's early rows (two idle half-steps per
+    // block: C3 step +1 %), which therefore keep the one-group loop; D = 64 runs two workgroups per CU in the one-group loop (125
+    // registers), which the two-group loop's 139 do not allow (0.45 against 0.53 ms); D = 256 has no registers for it.
+    // profiles/r04/time_16bit_v_mode_loop_forms.log, ab_c3_pv16_loop_forms.log
+    static_assert(!PP || D == 128, "the two-group loop is instantiated for D = 128");
+    constexpr int PW = (KP + NW - 1) / NW + VPW;        // LDS-DMA pieces per wave and stage: 2 / 3 / 6 (D = 64: see dma_stage)
     // The XOR that spreads the transposed reads over the banks, on the 16-byte chunk index of V row r (see the file header for D = 128).
     // A 32-lane half reads 4 rows (r & 3 = 0..3) x 64 bytes; a 64-byte granule covers 16 of the 64 banks, so the four rows' granules must
     // differ mod 4.  Rows are RB bytes apart: D = 128 / 256 (256 / 512 B, = 0 mod 256): XOR the granule index (chunk bits 2..3) with
@@ -116,12 +146,12 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
         unsigned char* dst = smem + slot * STAGE;
 #pragma unroll
         for (int r = 0; r < (KP + NW - 1) / NW; r++) {
-            const int pc = wave + NW * r;                       // (D = 64: waves 0 .. 3 only)
-            if (pc < KP) {
-                const unsigned char* ksrc = kg + (long)min(t, p.nchunks - 1) * CH + (pc << 10) + (lane << 4);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
-                                                 (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
-            }
+            // (D = 64: four pieces for eight waves -- waves 4 .. 7 fetch them once more, the same bytes to the same place: every wave then has
+            // the same number of requests in flight, which is what the counted waits below assume)
+            const int pc = (wave + NW * r) % KP;
+            const unsigned char* ksrc = kg + (long)min(t, p.nchunks - 1) * CH + (pc << 10) + (lane << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
+                                             (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < VPW; i++) {
@@ -134,17 +164,13 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
                                              (__attribute__((address_space(3))) void*)(dst + CH + (pc << 10)), 16, 0, 0);
         }
     };
-    // this wave's pieces per stage: the s_waitcnt immediate that leaves exactly the NEXT stage in flight
-    auto wait_stage = [&](bool next_in_flight) {
-        if (!next_in_flight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-        if constexpr (D == 64) {
-            if (wave < KP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        } else if constexpr (D == 128) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // waits until at most k STAGES requested after the one needed are still in flight (k workgroup-uniform; PW requests per wave and stage)
+    auto wait_younger = [&](int k) {
+        if (k <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW) : "memory");
     };
-    if (n_wg > 0) dma_stage(0, 0);
-    if (n_wg > 1) dma_stage(1, 1);
-
     // ---- Q^T fragments straight into registers: the lane's 32 bytes d = 64 s + 32 hh .. + 31 of its row
     v8i qf[KS];
     float c;
@@ -178,6 +204,9 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
         c = TOKEN ? p.sm_log2e * (qvalid ? p.sq[bh * p.Sq + qrow] : 1.0f) : p.sm_log2e * p.sq[bh] * p.sk[kv_head];
     }
     const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
+    // the ring's first stages, requested behind the Q loads (the counter is in order: waiting for a stage never waits for Q's successors)
+    int issued = 0;
+    for (; issued < (PP ? NS : 2) && issued < n_wg; issued++) dma_stage(issued, issued);
     // ---- per-lane pieces of the transposed-read addresses (T10): lane 4 q4 + p4 of a 16-lane group supplies row R + q4, the 8 bytes
     // at element 4 p4 of the group's 16 columns; the group's columns are d = 32 m + 16 cg .. + 15 (cg = group & 1), its rows start at
     // R = 32 tt + 16 s + 4 hh (elements 0..3 of the operand) and R + 8 (elements 4..7) -- the key order in which the S^T accumulator
@@ -195,109 +224,233 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     for (int m = 0; m < MB; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
-    float m_run = -1.0e30f, l_run = 0.0f;
+    float m_run = -1.0e30f;
+    // Row sums of the ROUNDED P on the matrix pipe: ones(16 x 32) . P^T with one v_mfma_f32_16x16x32 per k-step.  Read as that shape's B
+    // operand, a k-step's P registers are 16 queries x four 8-key groups {lanes 0-15: queries 0-15, keys 0-7 | 16-31: queries 16-31, keys
+    // 0-7 | 32-47: queries 0-15, keys 8-15 | 48-63: queries 16-31, keys 8-15}; A row 0 is one on the even groups, row 1 on the odd ones, so
+    // output row 0 (register 0 of lanes 0-15) sums query n's 16 keys and row 1 (register 1) query n + 16's (WaveState::lsum of the fp8
+    // sweeps, qattn_attn_v2.hip).  32 unpack-and-add pairs per chunk and lane become four 16-cycle products.
+    v4f lsum = {0.0f, 0.0f, 0.0f, 0.0f};
+    vec16 ones;
+    {
+        const int row = lane & 15, kgrp = lane >> 4;
+        const int one = ((row == 0 && !(kgrp & 1)) || (row == 1 && (kgrp & 1))) ? (int)T::kOnes : 0;
+        const v4i w = {one, one, one, one};
+        __builtin_memcpy(&ones, &w, 16);
+    }
 
-    int slot = 0;
-    for (int t = 0; t < n_wg; t++) {
-        // stage t has landed (this wave's three pieces; the stage behind it may still be in flight), then everyone's pieces are visible
-        // and every wave has left the slot that stage t + 2 is about to overwrite
-        wait_stage(t + 1 < n_wg);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < n_wg) dma_stage(t + 2, slot >= 1 ? slot - 1 : slot + 2);
-        if (t < n_w) {   // wave-uniform (causal: waves whose rows end earlier keep the barrier cadence)
-            const unsigned char* kbuf = smem + slot * STAGE + frag_lane_off;
-            const unsigned char* vbuf = smem + slot * STAGE + CH;
-            v16f s0, s1;
+    // ---- the three parts of a chunk's work
+    v16f s0, s1;        // S^T of the chunk between its QK^T and its softmax
+    vec16 pb[2][2];     // P of the chunk between its softmax and its PV: pb[tt][s] = the B operand of k-step s of tile tt
+    auto qk = [&](int t, int slot) {   // S^T(t) = K(t).Q^T
+        const unsigned char* kbuf = smem + slot * STAGE + frag_lane_off;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
+        for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                const v8i ka = lds_read_frag(kbuf + ((0 * KS + s) << 11)), kb = lds_read_frag(kbuf + ((1 * KS + s) << 11));
-                s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf[s], s0);
-                s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf[s], s1);
-            }
-            if constexpr (TOKEN) {
-                // per-key scales: registers 4 j .. 4 j + 3 of tile tt hold keys t 64 + 32 tt + 8 j + 4 hh .. + 3.  The 8 scales of (tt, j) sit at
-                // a wave-uniform address -- scalar loads, the lane's half picked by hh -- so they cost no vector registers (at D = 256 the
-                // pass has none to spare: 128 of O^T, 32 of Q^T, 32 of scores, 16 of P).  Keys beyond Skv: the last scale (masked below).
-#pragma unroll
-                for (int tt = 0; tt < 2; tt++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int kb = t * 64 + 32 * tt + 8 * j;
-                        const int last = p.Skv - 1;
-                        v16f& sx = tt ? s1 : s0;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const float wa = skt[min(kb + i, last)], wb = skt[min(kb + 4 + i, last)];
-                            sx[4 * j + i] *= hh ? wb : wa;
-                        }
-                    }
-            }
-            prep_scores<CAUSAL, false>(s0, s1, p, t * 64, q0, qrow, hh, nullptr);
-            float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
-            mx = fmaxf(mx, s0[15]);
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
-            {
-                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            if (__any((mx - m_run) * c > kPv16RescaleThr)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-#pragma unroll
-                for (int m = 0; m < MB; m++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) o[m][r] *= alpha;
-                l_run *= alpha;
-                m_run = m_new;
-            }
-            const float mc = -m_run * c;
-            // P: fp32 exponentials cast pairwise; pb[tt][s] = the B operand of k-step s of tile tt.  The row sum adds the ROUNDED values,
-            // so that numerator and denominator see the same weights and a row carried by one key reproduces that key's V row to the
-            // output rounding whatever the deferred reference is (the reference sums the un-rounded values, tk/attention.py:297-301;
-            // with its exact running max the top key's P is exactly 1 and the two agree there)
-            vec16 pb[2][2];
-            float ls = 0.0f;
+        for (int s = 0; s < KS; s++) {
+            const v8i ka = lds_read_frag(kbuf + ((0 * KS + s) << 11)), kb = lds_read_frag(kbuf + ((1 * KS + s) << 11));
+            s0 = mfma_f8<QK_FMT, QK_FMT>(ka, qf[s], s0);
+            s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf[s], s1);
+        }
+    };
+    auto softmax = [&](int t) {        // P(t) from S^T(t); may rescale O^T and the row sums
+        if constexpr (TOKEN) {
+            // per-key scales: registers 4 j .. 4 j + 3 of tile tt hold keys t 64 + 32 tt + 8 j + 4 hh .. + 3.  The 8 scales of (tt, j) sit at
+            // a wave-uniform address -- scalar loads, the lane's half picked by hh -- so they cost no vector registers (at D = 256 the
+            // pass has none to spare: 128 of O^T, 32 of Q^T, 32 of scores, 16 of P).  Keys beyond Skv: the last scale (masked below).
 #pragma unroll
             for (int tt = 0; tt < 2; tt++)
 #pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    const v16f& sx = tt ? s1 : s0;
-                    unsigned w[4];
+                for (int j = 0; j < 4; j++) {
+                    const int kb = t * 64 + 32 * tt + 8 * j;
+                    const int last = p.Skv - 1;
+                    v16f& sx = tt ? s1 : s0;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[8 * s + 2 * j], c, mc));
-                        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[8 * s + 2 * j + 1], c, mc));
-                        w[j] = T::pack2(e0, e1);
-                        ls += T::sum2(w[j]);
+                    for (int i = 0; i < 4; i++) {
+                        const float wa = skt[min(kb + i, last)], wb = skt[min(kb + 4 + i, last)];
+                        sx[4 * j + i] *= hh ? wb : wa;
                     }
-                    const v4i wv = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-                    __builtin_memcpy(&pb[tt][s], &wv, 16);
                 }
-            l_run += ls;
+        }
+        prep_scores<CAUSAL, false>(s0, s1, p, t * 64, q0, qrow, hh, nullptr);
+        float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
+        mx = fmaxf(mx, s0[15]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (__any((mx - m_run) * c > kPv16RescaleThr)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[m][r] *= alpha;
+            lsum[0] *= alpha;                                                        // lane n < 16: query n ...
+            lsum[1] *= __uint_as_float(swizzle_xor16(__float_as_uint(alpha)));       // ... and query n + 16 (lane n + 16's factor)
+            m_run = m_new;
+        }
+        const float mc = -m_run * c;
+        // P: fp32 exponentials cast pairwise; pb[tt][s] = the B operand of k-step s of tile tt.  The row sum adds the ROUNDED values,
+        // so that numerator and denominator see the same weights and a row carried by one key reproduces that key's V row to the
+        // output rounding whatever the deferred reference is (the reference sums the un-rounded values, tk/attention.py:297-301;
+        // with its exact running max the top key's P is exactly 1 and the two agree there)
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const v16f& sx = tt ? s1 : s0;
+                unsigned w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // (two v_fma_f32, not one v_pk_fma_f32: the packed form costs several issue slots -- MI355X_MICROARCH.md, constants table)
+                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[8 * s + 2 * j], c, mc));
+                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[8 * s + 2 * j + 1], c, mc));
+                    w[j] = T::pack2(e0, e1);
+                }
+                const v4i wv = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+                __builtin_memcpy(&pb[tt][s], &wv, 16);
+            }
+    };
+    auto pv = [&](int slot) {          // O^T += V^T.P^T and the row sums, V from ring slot `slot`
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) lsum = T::mfma_sum(ones, pb[tt][s], lsum);
+        const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(smem + slot * STAGE + CH);
+        if constexpr (D <= 128) {
+            // O^T += V^T.P^T, one k-step (16 keys) after the other over all MB column blocks: consecutive products go to DIFFERENT
+            // accumulators (four products in a row into one accumulator each waited for its predecessor's result: the products of a
+            // chunk took twice their pipe time), and the next k-step's transposed reads travel meanwhile
+            unsigned alo[MB], ahi[MB];
 #pragma unroll
             for (int m = 0; m < MB; m++) {
                 const unsigned xm = 64u * (unsigned)(m ^ qsw);
-                const unsigned char* alo = vbuf + tr_lo + xm;
-                const unsigned char* ahi = vbuf + tr_hi + xm;
+                alo[m] = vaddr + tr_lo + xm;
+                ahi[m] = vaddr + tr_hi + xm;
+            }
+            auto issue = [&](v2i32 (&r)[2 * MB], auto j_tag) {   // k-step j = 2 tt + s: keys 16 j .. 16 j + 15 of the chunk
+                constexpr int J = decltype(j_tag)::value;
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++)
+                for (int m = 0; m < MB; m++) {
+                    r[2 * m] = pv16_read_tr_at<RB * 16 * J>(alo[m]);
+                    r[2 * m + 1] = pv16_read_tr_at<RB * 16 * J>(ahi[m]);
+                }
+            };
+            auto multiply = [&](v2i32 (&r)[2 * MB], const vec16& pj) {
 #pragma unroll
-                    for (int s = 0; s < 2; s++) {
-                        const int roff = RB * (32 * tt + 16 * s);
-                        o[m] = T::mfma(pv16_read_vt<vec16>(alo + roff, ahi + roff), pb[tt][s], o[m]);
-                    }
+                for (int m = 0; m < MB; m++) o[m] = T::mfma(pv16_operand<vec16>(r[2 * m], r[2 * m + 1]), pj, o[m]);
+            };
+            using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+            using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+            v2i32 ra[2 * MB], rb[2 * MB];
+            issue(ra, J0{});
+            issue(rb, J1{});
+            pv16_wait_lds<2 * MB>(ra);
+            multiply(ra, pb[0][0]);
+            issue(ra, J2{});
+            pv16_wait_lds<2 * MB>(rb);
+            multiply(rb, pb[0][1]);
+            issue(rb, J3{});
+            pv16_wait_lds<2 * MB>(ra);
+            multiply(ra, pb[1][0]);
+            pv16_wait_lds<0>(rb);
+            multiply(rb, pb[1][1]);
+        } else {
+            // D = 256: no registers for a second set of operands: one 32-column block of V^T after the other -- read, wait, multiply
+            v2i32 ra[8];
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+                const unsigned xm = 64u * (unsigned)(m ^ qsw);
+                const unsigned alo = vaddr + tr_lo + xm, ahi = vaddr + tr_hi + xm;
+                ra[0] = pv16_read_tr_at<RB * 0>(alo);  ra[1] = pv16_read_tr_at<RB * 0>(ahi);
+                ra[2] = pv16_read_tr_at<RB * 16>(alo); ra[3] = pv16_read_tr_at<RB * 16>(ahi);
+                ra[4] = pv16_read_tr_at<RB * 32>(alo); ra[5] = pv16_read_tr_at<RB * 32>(ahi);
+                ra[6] = pv16_read_tr_at<RB * 48>(alo); ra[7] = pv16_read_tr_at<RB * 48>(ahi);
+                pv16_wait_lds<0>(ra);
+                o[m] = T::mfma(pv16_operand<vec16>(ra[0], ra[1]), pb[0][0], o[m]);
+                o[m] = T::mfma(pv16_operand<vec16>(ra[2], ra[3]), pb[0][1], o[m]);
+                o[m] = T::mfma(pv16_operand<vec16>(ra[4], ra[5]), pb[1][0], o[m]);
+                o[m] = T::mfma(pv16_operand<vec16>(ra[6], ra[7]), pb[1][1], o[m]);
             }
         }
-        slot = slot == kPv16Slots - 1 ? 0 : slot + 1;
+    };
+
+    if constexpr (!PP) {
+        // ---- one group: every wave runs QK^T -> softmax -> PV on chunk t between two barriers (3-slot ring, two stages ahead)
+        int slot = 0;
+        for (int t = 0; t < n_wg; t++) {
+            // stage t has landed (the stage behind it may still be in flight), then everyone's pieces are visible and every wave has left
+            // the slot that stage t + 2 is about to overwrite
+            wait_younger(issued - 1 - t);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (issued < n_wg) { dma_stage(issued, issued % NS); issued++; }
+            if (t < n_w) {   // wave-uniform (causal: waves whose rows end earlier keep the barrier cadence)
+                qk(t, slot);
+                softmax(t);
+                pv(slot);
+            }
+            slot = slot == NS - 1 ? 0 : slot + 1;
+        }
+    } else {
+        // ---- two groups of four waves, half a chunk apart (the two waves of a SIMD are one of each: waves w and w + 4).  Between two
+        // barriers one group runs its matrix products -- PV(t - 1) and QK^T(t) -- while the other runs its softmax: with every wave in the
+        // same phase, as in the one-group form, both waves of a SIMD want the matrix pipe, then both want the vector pipe, and the
+        // passes of a block ran at the SUM of the two (D = 128, C2 shape: 2930 cycles per chunk for 1536 of products).
+        //   half-step 2u    : group 0: PV(u-1), QK(u)      group 1: softmax(u-1)
+        //   half-step 2u + 1: group 0: softmax(u)          group 1: PV(u-1), QK(u)
+        // Stage t = {K(t), V(t)} is read from half-step 2t (group 0's QK) to 2t + 3 (group 1's PV): its slot takes stage t + NS at
+        // half-step 2t + 4, which must have landed by 2t + 2 NS.
+        // (waves w and w + 4 share a SIMD: with the groups cut as wave & 1 or (wave >> 1) & 1 the same pass took 1.15 / 1.04 ms against 0.91)
+        const int grp = wave >> 2;
+        auto products = [&](int u) {
+            if (u >= 1 && u - 1 < n_w) pv((u - 1) % NS);
+            if (u < n_w) qk(u, u % NS);
+        };
+        wait_younger(issued - 1);
+        __builtin_amdgcn_s_barrier();
+        // (two loops, one per group, each a straight sequence of its two phases: with one loop and the phase picked inside it the
+        // accumulators met at the join of the two branches and the compiler copied them around -- 400 register moves per trip, spills)
+        auto top = [&](int u) {
+            asm volatile("" ::: "memory");
+            if (u >= 2 && issued < n_wg) { dma_stage(issued, issued % NS); issued++; }   // (stage u - 2's slot: free since the barrier above)
+        };
+        auto mid = [&]() {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto tail = [&](int u) {
+            if (u + 1 < n_wg) wait_younger(issued - 2 - u);   // stage u + 1, needed from the next half-step on
+            __builtin_amdgcn_s_barrier();
+        };
+        if (grp == 0) {
+#pragma nounroll
+            for (int u = 0; u <= n_wg; u++) {
+                top(u);
+                products(u);
+                mid();
+                if (u < n_w) softmax(u);
+                tail(u);
+            }
+        } else {
+#pragma nounroll
+            for (int u = 0; u <= n_wg; u++) {
+                top(u);
+                if (u >= 1 && u - 1 < n_w) softmax(u - 1);
+                mid();
+                products(u);
+                tail(u);
+            }
+        }
     }
-    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
+    const float l_lo = bcast_low16(lsum[0]), l_hi = bcast_low16(lsum[1]);
+    const float l_tot = (lane & 16) ? l_hi : l_lo;
     const unsigned ticket = draw_issue_hook();
     store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_tot, bh * p.Sq + qrow, hh, qvalid);
     draw_finish_hook(ticket);
