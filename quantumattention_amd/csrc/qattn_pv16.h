@@ -80,6 +80,14 @@ __device__ __forceinline__ void pv16_wait_lds(v2i32 (&r)[8]) {
                  : "memory");
 }
 template <int N>
+__device__ __forceinline__ void pv16_wait_lds(v2i32 (&r)[8], v2i32 (&q)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%16)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]),
+                   "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
 __device__ __forceinline__ void pv16_wait_lds(v2i32 (&r)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
 }
@@ -142,27 +150,44 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
 
     // ---- one ring stage by LDS-DMA: K chunk t (KP pieces of 1 KiB over the waves) and V rows 64 t .. 64 t + 63 (VPW pieces of RPP rows per wave)
     const int vr = lane / CPR, vc = lane % CPR;                // row within a piece / 16-byte chunk within the row this lane copies
-    auto dma_stage = [&](int t, int slot) {
-        unsigned char* dst = smem + slot * STAGE;
+    // (per-lane source addresses of the wave's pieces within chunk 0, computed once per block: per stage a uniform offset is added)
+    constexpr int KPW = (KP + NW - 1) / NW;
+    const unsigned char* ksrc0[KPW];
+    const unsigned char* vsrc0[VPW];
 #pragma unroll
-        for (int r = 0; r < (KP + NW - 1) / NW; r++) {
-            // (D = 64: four pieces for eight waves -- waves 4 .. 7 fetch them once more, the same bytes to the same place: every wave then has
-            // the same number of requests in flight, which is what the counted waits below assume)
-            const int pc = (wave + NW * r) % KP;
-            const unsigned char* ksrc = kg + (long)min(t, p.nchunks - 1) * CH + (pc << 10) + (lane << 4);
+    for (int r = 0; r < KPW; r++) {
+        // (D = 64: four pieces for eight waves -- waves 4 .. 7 fetch them once more, the same bytes to the same place: every wave then has
+        // the same number of requests in flight, which is what the counted waits below assume)
+        const int pc = (wave + NW * r) % KP;
+        ksrc0[r] = kg + (pc << 10) + (lane << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; i++) {
+        const int r = RPP * (wave * VPW + i) + vr;
+        vsrc0[i] = vg + (long)r * RB + ((vc ^ swz(r)) << 4);
+    }
+    // piece i of the wave's PW pieces of stage t (K pieces first), into ring slot `slot`
+    auto dma_piece = [&](int i, int t, int slot) {
+        unsigned char* dst = smem + slot * STAGE;
+        if (i < KPW) {
+            const int pc = (wave + NW * i) % KP;
+            const unsigned char* ksrc = ksrc0[i < KPW ? i : 0] + (long)min(t, p.nchunks - 1) * CH;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
                                              (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < VPW; i++) {
-            const int pc = wave * VPW + i;
-            const int r = RPP * pc + vr;
-            const int key = min(t * 64 + r, p.Skv - 1);
-            const int ch = vc ^ swz(r);
-            const unsigned char* vsrc = vg + (long)key * RB + (ch << 4);
+        } else {
+            const int j = i - KPW, pc = wave * VPW + j;
+            const unsigned char* vsrc = vsrc0[j >= 0 && j < VPW ? j : 0] + (long)t * (64 * RB);
+            if (t * 64 + 64 > p.Skv) {   // (workgroup-uniform) the head's last, ragged chunk: keys beyond Skv re-read the last row
+                const int r = RPP * pc + vr;
+                vsrc = vg + (long)min(t * 64 + r, p.Skv - 1) * RB + ((vc ^ swz(r)) << 4);
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
                                              (__attribute__((address_space(3))) void*)(dst + CH + (pc << 10)), 16, 0, 0);
         }
+    };
+    auto dma_stage = [&](int t, int slot) {
+#pragma unroll
+        for (int i = 0; i < PW; i++) dma_piece(i, t, slot);
     };
     // waits until at most k STAGES requested after the one needed are still in flight (k workgroup-uniform; PW requests per wave and stage)
     auto wait_younger = [&](int k) {
@@ -253,7 +278,8 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
             s1 = mfma_f8<QK_FMT, QK_FMT>(kb, qf[s], s1);
         }
     };
-    auto softmax = [&](int t) {        // P(t) from S^T(t); may rescale O^T and the row sums
+    auto no_hook = [](int) {};
+    auto softmax = [&](int t, auto&& hook) {        // P(t) from S^T(t); may rescale O^T and the row sums.  hook(0 .. 2): three points spread over it
         if constexpr (TOKEN) {
             // per-key scales: registers 4 j .. 4 j + 3 of tile tt hold keys t 64 + 32 tt + 8 j + 4 hh .. + 3.  The 8 scales of (tt, j) sit at
             // a wave-uniform address -- scalar loads, the lane's half picked by hh -- so they cost no vector registers (at D = 256 the
@@ -295,6 +321,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
             m_run = m_new;
         }
         const float mc = -m_run * c;
+        hook(0);
         // P: fp32 exponentials cast pairwise; pb[tt][s] = the B operand of k-step s of tile tt.  The row sum adds the ROUNDED values,
         // so that numerator and denominator see the same weights and a row carried by one key reproduces that key's V row to the
         // output rounding whatever the deferred reference is (the reference sums the un-rounded values, tk/attention.py:297-301;
@@ -314,6 +341,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
                 }
                 const v4i wv = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
                 __builtin_memcpy(&pb[tt][s], &wv, 16);
+                if (s == 1) hook(1 + tt);
             }
     };
     auto pv = [&](int slot) {          // O^T += V^T.P^T and the row sums, V from ring slot `slot`
@@ -392,7 +420,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
             if (issued < n_wg) { dma_stage(issued, issued % NS); issued++; }
             if (t < n_w) {   // wave-uniform (causal: waves whose rows end earlier keep the barrier cadence)
                 qk(t, slot);
-                softmax(t);
+                softmax(t, no_hook);
                 pv(slot);
             }
             slot = slot == NS - 1 ? 0 : slot + 1;
@@ -408,17 +436,68 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
         // half-step 2t + 4, which must have landed by 2t + 2 NS.
         // (waves w and w + 4 share a SIMD: with the groups cut as wave & 1 or (wave >> 1) & 1 the same pass took 1.15 / 1.04 ms against 0.91)
         const int grp = wave >> 2;
-        auto products = [&](int u) {
-            if (u >= 1 && u - 1 < n_w) pv((u - 1) % NS);
-            if (u < n_w) qk(u, u % NS);
+        // PV(u - 1) and QK^T(u) as one sequence: all a trip's LDS latency in one place.  The first two k-steps' transposed reads and the K
+        // fragments are requested together; QK^T runs as soon as K is there (the row-sum products cover part of that wait), the other two
+        // k-steps' reads are requested behind it and land under the first eight PV products.  (Requested one k-step ahead, as pv() does it,
+        // every k-step waited ~150 cycles for its operands: 1400 cycles per trip for 830 of products -- dev stamps, tools/pv16_phases.py.)
+        auto pv_qk = [&](int slot_v, int slot_k) {
+            static_assert(MB == 4, "register sets of eight transposed reads");
+            const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(smem + slot_v * STAGE + CH);
+            unsigned alo[MB], ahi[MB];
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+                const unsigned xm = 64u * (unsigned)(m ^ qsw);
+                alo[m] = vaddr + tr_lo + xm;
+                ahi[m] = vaddr + tr_hi + xm;
+            }
+            v2i32 ra[8], rb[8], rc[8];   // (a fourth set does not fit 256 registers: the last k-step re-uses the first one's, once its products are long gone)
+#pragma unroll
+            for (int m = 0; m < MB; m++) { ra[2 * m] = pv16_read_tr_at<RB * 0>(alo[m]); ra[2 * m + 1] = pv16_read_tr_at<RB * 0>(ahi[m]); }
+#pragma unroll
+            for (int m = 0; m < MB; m++) { rb[2 * m] = pv16_read_tr_at<RB * 16>(alo[m]); rb[2 * m + 1] = pv16_read_tr_at<RB * 16>(ahi[m]); }
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) lsum = T::mfma_sum(ones, pb[tt][s], lsum);
+            qk(0, slot_k);   // (the chunk index is not used by qk)
+#pragma unroll
+            for (int m = 0; m < MB; m++) { rc[2 * m] = pv16_read_tr_at<RB * 32>(alo[m]); rc[2 * m + 1] = pv16_read_tr_at<RB * 32>(ahi[m]); }
+            pv16_wait_lds<8>(ra, rb);
+#pragma unroll
+            for (int m = 0; m < MB; m++) o[m] = T::mfma(pv16_operand<vec16>(ra[2 * m], ra[2 * m + 1]), pb[0][0], o[m]);
+#pragma unroll
+            for (int m = 0; m < MB; m++) o[m] = T::mfma(pv16_operand<vec16>(rb[2 * m], rb[2 * m + 1]), pb[0][1], o[m]);
+            // (k-step 0's four products were issued 128 pipe cycles ago: their operands have been read)
+#pragma unroll
+            for (int m = 0; m < MB; m++) { ra[2 * m] = pv16_read_tr_at<RB * 48>(alo[m]); ra[2 * m + 1] = pv16_read_tr_at<RB * 48>(ahi[m]); }
+            pv16_wait_lds<8>(rc);
+#pragma unroll
+            for (int m = 0; m < MB; m++) o[m] = T::mfma(pv16_operand<vec16>(rc[2 * m], rc[2 * m + 1]), pb[1][0], o[m]);
+            pv16_wait_lds<0>(ra);
+#pragma unroll
+            for (int m = 0; m < MB; m++) o[m] = T::mfma(pv16_operand<vec16>(ra[2 * m], ra[2 * m + 1]), pb[1][1], o[m]);
         };
+        // One code path for every trip: the first one multiplies chunk 0's V by P = 0 (pb starts as zeros), the wave's last one computes a
+        // QK^T nobody reads (on whatever the slot holds).  Separate PV-only / QK^T-only paths cost registers the loop does not have.
+        auto products = [&](int u) {
+            if (u <= n_w) pv_qk(u >= 1 ? (u - 1) % NS : 0, u % NS);
+        };
+        {
+            const v4i z = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; i++) __builtin_memcpy(&pb[i >> 1][i & 1], &z, 16);
+        }
         wait_younger(issued - 1);
         __builtin_amdgcn_s_barrier();
         // (two loops, one per group, each a straight sequence of its two phases: with one loop and the phase picked inside it the
         // accumulators met at the join of the two branches and the compiler copied them around -- 400 register moves per trip, spills)
-        auto top = [&](int u) {
+        // Each group requests its pieces of the next stage at the head of its SOFTMAX phase (the matrix pipe does not wait for the 360 .. 660
+        // issue cycles of three requests, dev stamps).  Spread over the phase -- one request after each third of the exponentials -- they
+        // cost MORE: the phase grew from 1520 to 1980 cycles (profiles/r04/pv16_phase_stamps.log).
+        auto softmax_and_dma = [&](int u, bool do_softmax, int t) {
             asm volatile("" ::: "memory");
-            if (u >= 2 && issued < n_wg) { dma_stage(issued, issued % NS); issued++; }   // (stage u - 2's slot: free since the barrier above)
+            if (u >= 2 && issued < n_wg) { dma_stage(issued, issued % NS); issued++; }   // (stage u - 2's slot: free since the last barrier but one)
+            if (do_softmax) softmax(t, no_hook);
         };
         auto mid = [&]() {
             __builtin_amdgcn_s_barrier();
@@ -428,25 +507,42 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
             if (u + 1 < n_wg) wait_younger(issued - 2 - u);   // stage u + 1, needed from the next half-step on
             __builtin_amdgcn_s_barrier();
         };
+#ifdef QATTN_PV16_STAMP   // development: cycles per phase, summed over the sweep, written over the wave's first LSE entries
+        unsigned long long acc[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define PV16_T(I) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc[I] += t_ - tl; tl = t_; } while (0)
+#else
+#define PV16_T(I) do { } while (0)
+#endif
         if (grp == 0) {
 #pragma nounroll
             for (int u = 0; u <= n_wg; u++) {
-                top(u);
                 products(u);
+                PV16_T(0);
                 mid();
-                if (u < n_w) softmax(u);
+                PV16_T(2);
+                softmax_and_dma(u, u < n_w, u);
+                PV16_T(1);
                 tail(u);
+                PV16_T(3);
             }
         } else {
 #pragma nounroll
             for (int u = 0; u <= n_wg; u++) {
-                top(u);
-                if (u >= 1 && u - 1 < n_w) softmax(u - 1);
+                softmax_and_dma(u, u >= 1 && u - 1 < n_w, u - 1);
+                PV16_T(1);
                 mid();
+                PV16_T(2);
                 products(u);
+                PV16_T(0);
                 tail(u);
+                PV16_T(3);
             }
         }
+#ifdef QATTN_PV16_STAMP
+        if (p.lse && lane == 0 && q0 + 8 <= p.Sq)
+            for (int i = 0; i < 5; i++) p.lse[bh * p.lse_stride + q0 + 1 + i] = (float)acc[i];
+#endif
+#undef PV16_T
     }
     // query q's sum sits in lane q & 15, register q >> 4 (both half-waves' keys already added by the MFMA)
     const float l_lo = bcast_low16(lsum[0]), l_hi = bcast_low16(lsum[1]);
@@ -454,7 +550,9 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     const unsigned ticket = draw_issue_hook();
     store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_tot, bh * p.Sq + qrow, hh, qvalid);
     draw_finish_hook(ticket);
+#ifndef QATTN_PV16_STAMP
     if (p.lse && hh == 0 && qvalid) p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c) + __logf(l_tot)) * p.lse_mul;
+#endif
 }
 
 // The 16-bit-V form of qattn_fp8_attention_forward (v_fmt = QATTN_FMT_BF16 / _FP16): every query block through pv16_block_pass, one
