@@ -493,7 +493,8 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
         // accumulators met at the join of the two branches and the compiler copied them around -- 400 register moves per trip, spills)
         // Each group requests its pieces of the next stage at the head of its SOFTMAX phase (the matrix pipe does not wait for the 360 .. 660
         // issue cycles of three requests, dev stamps).  Spread over the phase -- one request after each third of the exponentials -- they
-        // cost MORE: the phase grew from 1520 to 1980 cycles (profiles/r04/pv16_phase_stamps.log).
+        // cost MORE: the phase grew from 1520 to 1980 cycles; behind the last product of the products phase (the shorter one) they cost 500 ..
+        // 670 and the pass got 3 % slower (profiles/r04/pv16_phase_stamps.log).
         auto softmax_and_dma = [&](int u, bool do_softmax, int t) {
             asm volatile("" ::: "memory");
             if (u >= 2 && issued < n_wg) { dma_stage(issued, issued % NS); issued++; }   // (stage u - 2's slot: free since the last barrier but one)
