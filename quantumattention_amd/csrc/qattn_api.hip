@@ -185,12 +185,14 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     const bool prof = ds != nullptr;
     if (prof) (void)hipEventRecord(ds->prof[0], st);
     int rc = QATTN_OK;
+    hipStream_t side = nullptr;
     if (!v_is_16 && use_v2 && p.v16 != nullptr && p.q16 == nullptr && p.lse == nullptr) {
         // fused step on the D = 128 kernel WITHOUT in-kernel Q quantisation (fp16 inputs): its early rows through a 16-bit-V launch of
         // their own, the main launch skips those blocks (the bf16 fused step has the pass inside its kernel)
         const int n_early = pv16_early_blocks(a.Sq, a.Skv, a.is_causal, p.two_term_keys);
         if (n_early > 0) {
-            rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.out_fmt, a.is_causal, a.scale_mode, st, n_early);
+            if (n_early < p.nqb) side = side_stream_fork(st);   // (beside the main launch: disjoint rows, see launch_v4_full_d)
+            rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.out_fmt, a.is_causal, a.scale_mode, side ? side : st, n_early);
             p.skip_early = 1;
         }
     }
@@ -198,6 +200,10 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     else if (v_is_16) rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
     else if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     else rc = launch_attn_v4_full(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
+    if (side) {
+        const int rj = side_stream_join(st, side);
+        if (rc == QATTN_OK) rc = rj;
+    }
     if (prof) { (void)hipEventRecord(ds->prof[1], st); ds->recorded = true; }
     if (rc != QATTN_OK) return rc;
 #ifdef QATTN_DEV
@@ -346,6 +352,40 @@ bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
 }  // namespace
 
 namespace qattn {
+// ---- side stream (declared in qattn_attn.h)
+struct SideStream {
+    bool ready = false;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+thread_local SideStream t_side[kMaxDevices];
+
+#ifndef QATTN_SIDE_STREAM
+#define QATTN_SIDE_STREAM 1   // (a build knob for tools/ab.py variants: 0 = every launch of a call on the caller's stream)
+#endif
+hipStream_t side_stream_fork(hipStream_t st) {
+    if (!QATTN_SIDE_STREAM) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    SideStream& x = t_side[dev];
+    if (!x.ready) {
+        if (stream_is_capturing(st)) return nullptr;   // (no object creation inside a capture)
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        x.ready = true;
+    }
+    if (hipEventRecord(x.fork, st) != hipSuccess || hipStreamWaitEvent(x.s, x.fork, 0) != hipSuccess) return nullptr;
+    return x.s;
+}
+int side_stream_join(hipStream_t st, hipStream_t side) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return QATTN_ERR_LAUNCH;
+    SideStream& x = t_side[dev];
+    if (!x.ready || side != x.s) return QATTN_ERR_LAUNCH;
+    if (hipEventRecord(x.join, side) != hipSuccess || hipStreamWaitEvent(st, x.join, 0) != hipSuccess) return QATTN_ERR_LAUNCH;
+    return QATTN_OK;
+}
+
 __global__ void zero_words_kernel(unsigned* w, long n) {   // (declared in qattn_attn.h: zero_words)
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] = 0u;

@@ -680,6 +680,14 @@ __device__ __forceinline__ void rescue_rows(const AttnParams& p, unsigned char* 
                                                                      skt, qfrag, vx);
 }
 
+// A second stream for launches of one call that do not depend on each other (qattn_api.hip): the early rows of a causal call -- a few
+// hundred short, latency-bound workgroups -- beside the main launch.  fork: `side` waits for everything on `st` so far; join: `st` waits
+// for everything on `side`.  One stream and two events per host thread and device, created on first use outside a stream capture; nullptr
+// (run the launches one after the other on `st`) while capturing before that first use, or when creation fails.  Inside a capture the
+// fork / join pair becomes two parallel branches of the graph.
+hipStream_t side_stream_fork(hipStream_t st);
+int side_stream_join(hipStream_t st, hipStream_t side);
+
 // kernel-file entry points (one translation unit per operand format / head dimension, see build.py)
 int launch_attn_v2_e4m3(const AttnParams& p, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v2_e5m2(const AttnParams& p, int causal, int scale_mode, hipStream_t st);

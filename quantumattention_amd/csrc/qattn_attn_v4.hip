@@ -475,17 +475,25 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
         if (zero_words(p.flags, (long)p.B * p.Hq * ceil_div(p.Sq, 32), st) != hipSuccess) return QATTN_ERR_LAUNCH;
     }
     int rc = QATTN_OK;
-    if (rows_two < p.Sq)
-        rc = byte_exp ? launch_v4_d<D, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
-                      : launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
+    // The rows that run two-term (or on the 16-bit V) from the start and the rest are disjoint pieces of the output with nothing
+    // between them: where both exist -- a causal call -- the early rows go to a second stream, beside the main launch.  They are a few
+    // hundred short workgroups whose chunks wait for one memory round trip each; alone on the chip they took 87 of the 297 us of a D = 64
+    // causal AUTO call at B4 H32 S4096 (profiles/r04/trace_d64_causal_auto.txt).
+    hipStream_t side = nullptr;
+    if (rows_two > 0 && rows_two < p.Sq) side = side_stream_fork(st);
+    hipStream_t st_e = side ? side : st;
+    // (requested FIRST: their serial chains of memory round trips start at once, the main launch's workgroups fill the CUs around them)
     // the fused step (D = 64 / 256, and D = 128 with token-wise scales): the query blocks that see fewer than two_term_keys keys attend the ORIGINAL
     // 16-bit V with 16-bit P (qattn_pv16.h) instead of two-term fp8 P on the fp8 V; the rest of rows_two (ACCURATE) stays two-term
     int rows_early = 0;
     if (p.v16 != nullptr && p.lse == nullptr) {
         rows_early = min(rows_two, pv16_early_blocks(p.Sq, p.Skv, causal, p.two_term_keys) * 256);
-        if (rc == QATTN_OK && rows_early > 0) rc = launch_attn_pv16(p, D, fmt, p.out_fmt, causal, scale_mode, st, rows_early / 256);
+        if (rc == QATTN_OK && rows_early > 0) rc = launch_attn_pv16(p, D, fmt, p.out_fmt, causal, scale_mode, st_e, rows_early / 256);
     }
-    if (rc == QATTN_OK && rows_two > rows_early) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_early, rows_two, 1, st);
+    if (rc == QATTN_OK && rows_two > rows_early) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_early, rows_two, 1, st_e);
+    if (rc == QATTN_OK && rows_two < p.Sq)
+        rc = byte_exp ? launch_v4_d<D, true>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st)
+                      : launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, 0, st);
     // flagged 32-row groups: rescued one by one where a 256-row block has few of them, else the block is redone
     // (D = 256 with token-wise scales: the rescue loop does not fit 256 registers beside 128 of O^T -- every flagged block is redone)
     const bool group_rescue = !(D == 256 && scale_mode == QATTN_SCALE_TOKEN);
@@ -495,6 +503,10 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
         if (rc == QATTN_OK && rescue && group_rescue) rc = launch_rescue_head<D>(p, fmt, causal, rows_two, st);
     }
     if (rc == QATTN_OK && rescue) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, group_rescue ? 3 : 7, st);
+    if (side) {   // (joined on every path: a capture must not end with the side stream still forked)
+        const int rj = side_stream_join(st, side);
+        if (rc == QATTN_OK) rc = rj;
+    }
     return rc;
 }
 
