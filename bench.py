@@ -536,6 +536,30 @@ def run_rank(args):
                                  "max_abs_vs_oracle": acc_w["max_abs_vs_oracle"], "oracle_bound": acc_w["oracle_bound"],
                                  "max_abs_vs_16bitV": acc_w["max_abs_vs_16bitV"], "q_multiplier": mul}
                     del qw
+            # the reference kernel's own P.V numerics as a mode (fp8 QK^T, 16-bit P, the ORIGINAL 16-bit V: csrc/qattn_pv16.h,
+            # tk/attention.py:72,286,318): attention launch on pre-quantised q, k at the bench shape, and its distance to fp64 SDPA with
+            # the 16-bit V (what the reference kernel computes up to its own 16-bit P).  Context, never `value`.
+            try:
+                fd = _native.FP8_DTYPE[args.fp8]
+                q8m, sqm = _native.quant_fp8(q, fp8_dtype=fd)
+                kfm, skm = _native.quant_fp8(k, fp8_dtype=fd, layout=_native.LAYOUT_KFRAG)
+                fn16 = lambda: _native.fp8_attention_forward(q8m, kfm, v, sqm, skm, None, Hkv=H, Skv=S, out_dtype=torch.bfloat16, is_causal=args.causal)
+                ms16 = event_time(fn16, 20)
+                o16 = fn16()
+                q8s, sqs = _native.quant_fp8(q[:1, :1].contiguous(), fp8_dtype=fd)
+                k8s, sks = _native.quant_fp8(k[:1, :1].contiguous(), fp8_dtype=fd)
+                r1 = min(1024, S)
+                sc = ((q8s[0, 0, :r1].float().double() * float(sqs[0, 0])) @ (k8s[0, 0].float().double() * float(sks[0, 0])).T) / D ** 0.5
+                if args.causal:
+                    sc = sc.masked_fill(torch.arange(S, device=sc.device)[None, :] > torch.arange(r1, device=sc.device)[:, None], float("-inf"))
+                ref16 = torch.softmax(sc, dim=1) @ v[0, 0].double()
+                line["reference_numerics_mode"] = {
+                    "attn_kernel_ms": ms16, "attn_TFLOPs": f_gpu / (ms16 * 1e-3) / 1e12,
+                    "max_abs_vs_16bitV": float((o16[0, 0, :r1].double() - ref16).abs().max()), "bound": 2.0 ** -7 * max(1.0, float(ref16.abs().max())),
+                    "note": "qattn_fp8_attention_forward(v_fmt = bf16): fp8 QK^T, bf16 P, original bf16 V; slice batch 0, head 0, rows [0, 1024)"}
+                del q8m, kfm, o16
+            except Exception as exc:
+                print(f"[bench] 16-bit-V mode sample skipped: {exc}", file=sys.stderr)
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
             def extra(Bx, Hx, Sx, causal, fp8, n):
                 qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
