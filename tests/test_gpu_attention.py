@@ -334,6 +334,60 @@ def test_hip_graph_capture_of_the_whole_step(B, H, S):
         assert torch.equal(out16, qa.attn_func(q, k, v))
 
 
+@pytest.mark.parametrize("D,token", [(64, False), (256, False), (128, True)])
+def test_second_stream_of_the_early_rows_under_capture_and_from_two_threads(D, token):
+    """Causal calls on the templated kernel run their early rows on an internal second stream, forked from and joined to the caller's
+    stream inside the call (csrc/qattn_api.hip side_stream_fork / _join).  (i) Captured in a HIP graph the pair must become part of the
+    capture and replay to the eager bits on new data; (ii) two host threads, each on its own stream (each gets its own internal
+    stream), must both get the single-threaded bits; (iii) a consumer queued on the caller's stream right behind the call sees the
+    early rows (the join orders it)."""
+    import threading
+    fn = qa.fp8_token_wise_attn_func if token else qa.fp8_attn_func
+    torch.manual_seed(D)
+    B, H, S = 2, 4, 2304
+    q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    want = fn(q, k, v, is_causal=True)
+    assert torch.isfinite(want).all()
+    # (iii) the early rows (first 1024) summed on the same stream right behind the call
+    tot = fn(q, k, v, is_causal=True)[:, :, :1024].float().sum()
+    assert torch.equal(tot, want[:, :, :1024].float().sum())
+    # (i)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn(q, k, v, is_causal=True)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn(q, k, v, is_causal=True)
+    q2, k2, v2 = (torch.randn_like(t) for t in (q, k, v))
+    want2 = fn(q2, k2, v2, is_causal=True)
+    q.copy_(q2); k.copy_(k2); v.copy_(v2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want2)
+    # (ii)
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(st):
+                for _ in range(5):
+                    r = fn(q, k, v, is_causal=True)
+                st.synchronize()
+            results[i] = r
+        except Exception as exc:   # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    assert torch.equal(results[0], want2) and torch.equal(results[1], want2)
+
+
 @pytest.mark.parametrize("backend", ["eager", "aot_eager", "inductor"])
 def test_torch_compile_traces_the_ops_as_opaque_calls(backend):
     """inside a user's torch.compile region the custom ops are traced through their fake impls
