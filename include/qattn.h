@@ -18,7 +18,12 @@
  *   - plain C, no torch types; every pointer is a DEVICE pointer on the current HIP device;
  *   - tensors are dense [B, H, S, D] ("row-major") unless a fragment layout is named;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls enqueue work and return
- *     immediately -- no host synchronisation, no allocation, graph-capture safe;
+ *     immediately -- no host synchronisation, no allocation, graph-capture safe.  In stream order a call begins after everything
+ *     queued on `stream` before it and ends before everything queued after it; inside, a causal attention call on the templated
+ *     kernel (D = 64 / 256, token-wise scales, fp16 inputs) runs the launch of its early rows on ONE internal non-blocking stream per
+ *     host thread and device, forked from and joined to `stream` with events (two parallel branches under capture).  That stream
+ *     and its two events are created on the thread's first such call outside a capture (a capturing call before that runs its
+ *     launches one after the other) and live until the process ends;
  *   - return 0 on success or a negative QATTN_ERR_* code; nothing is thrown; qattn_strerror() names the code.
  *
  * Fragment layouts (private to this library; produced by qattn_quant_fp8 / qattn_pack_fp8, consumed by the
