@@ -501,10 +501,13 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     const float* ext_amax[3] = {amax_q, amax_k, amax_v};
     // the hand-out counters of the attention launch (D = 128 kernel) are cleared by the quantise pass on its way: a launch of
     // its own for 32 bytes sat between the two kernels for ~5 us
-    const bool zero_in_prepass = attn_v2_covers(D, is_causal, scale_mode);
+    // (the templated kernel's AUTO launches start from cleared peaked-group flags, which live behind the counters: cleared on the same way)
+    const bool zero_in_prepass = attn_ws != nullptr;
+    const size_t zero_bytes = attn_v2_covers(D, is_causal, scale_mode) ? sched_bytes()
+                              : precision == QATTN_PRECISION_AUTO ? attn_ws_sched_bytes(B, Hq, Sq) + attn_ws_flag_bytes(B, Hq, Sq) : 0;
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
-                              numerics, ws, fuse_q, moments, v_block, st, ext_amax, zero_in_prepass ? (unsigned*)attn_ws : nullptr,
-                              zero_in_prepass ? (int)(sched_bytes() / sizeof(unsigned)) : 0);
+                              numerics, ws, fuse_q, moments, v_block, st, ext_amax, zero_in_prepass && zero_bytes ? (unsigned*)attn_ws : nullptr,
+                              zero_in_prepass ? (int)(zero_bytes / sizeof(unsigned)) : 0);
     if (rc != QATTN_OK) return rc;
     const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
     const bool q_ext = amax_q != nullptr;

@@ -472,7 +472,8 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
     const bool rescue = p.peak_r0 > 0.0f && rows_two < p.Sq;
     if (rescue) {
         if (!p.flags) return QATTN_ERR_WORKSPACE;
-        if (zero_words(p.flags, (long)p.B * p.Hq * ceil_div(p.Sq, 32), st) != hipSuccess) return QATTN_ERR_LAUNCH;
+        // (fused step: the quantise pass cleared them on its way, sched_zeroed)
+        if (!p.sched_zeroed && zero_words(p.flags, (long)p.B * p.Hq * ceil_div(p.Sq, 32), st) != hipSuccess) return QATTN_ERR_LAUNCH;
     }
     int rc = QATTN_OK;
     // The rows that run two-term (or on the 16-bit V) from the start and the rest are disjoint pieces of the output with nothing

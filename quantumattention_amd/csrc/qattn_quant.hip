@@ -95,7 +95,7 @@ struct QuantJobs {
     unsigned* vexp;       // block-scaled V (else nullptr): [G of v][kMomentSplits] E8M0 bytes, one per 64-key chunk
     int nsplit;           // abs-max-pass blocks per head = valid entries of amax_part / part per head
     int zmap[3];          // abs-max pass: blockIdx.z -> job (the tensors that still need the pass)
-    unsigned* zero_words; // quantise pass: zero_n (<= 256) words that its first block clears for the kernel that follows (else nullptr)
+    unsigned* zero_words; // quantise pass: zero_n words that its blocks clear between them for the kernel that follows (else nullptr)
     int zero_n;
 };
 
@@ -195,7 +195,10 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     const int S = jb.S;
     // a block takes kQuantTilesPerBlock consecutive tiles (downwards); the next tile's rows are requested before the current one is
     // converted, so a block has loads in flight all the time instead of one latency-bound burst per 16 KiB
-    if (jobs.zero_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < jobs.zero_n) jobs.zero_words[tid] = 0u;
+    if (jobs.zero_words) {   // (every block takes a stride of them: 32 bytes of hand-out counters, or those and the peaked-group flags)
+        const int nb = (int)(gridDim.x * gridDim.y * gridDim.z), lin = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        for (int i = lin * (int)blockDim.x + tid; i < jobs.zero_n; i += nb * (int)blockDim.x) jobs.zero_words[i] = 0u;
+    }
     const int g = jb.G - 1 - (int)blockIdx.y, tile_first = (S + 63) / 64 - 1 - (int)blockIdx.x * kQuantTilesPerBlock;
     if (g < 0 || tile_first < 0) return;
     const int layout = jb.layout;
