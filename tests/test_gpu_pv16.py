@@ -52,6 +52,11 @@ CASES = [
     (1, 2, 2, 640, 640, True, "e4m3", torch.float16, "head-wise"),
     (1, 2, 1, 1100, 1100, True, "e4m3", torch.bfloat16, "token-wise"),
     (1, 2, 2, 513, 700, False, "e5m2", torch.float16, "token-wise"),
+    # fewer chunks than ring stages: the loops' prologues and the last trips (D = 128: the two-group loop's four-stage ring)
+    (1, 2, 2, 40, 40, False, "e4m3", torch.bfloat16, "head-wise"),
+    (1, 2, 1, 70, 70, True, "e4m3", torch.bfloat16, "head-wise"),
+    (2, 2, 2, 129, 129, True, "e4m3", torch.float16, "token-wise"),
+    (1, 3, 3, 300, 65, False, "e5m2", torch.bfloat16, "head-wise"),
 ]
 
 
