@@ -18,7 +18,10 @@ BUILD = os.path.join(HERE, "_build")
 # directory of its own that neither git nor gpurun ships (.gitignore, .gpurunignore); the objects of the shipped library do not
 BUILD_TEMPS = os.path.join(HERE, "_build_temps")
 LIB = os.path.join(HERE, "libqattn_hip.so")
-SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip", "qattn_attn_pv16.hip"]
+# the dev library (ablations, cycle stamps, QATTN_* environment switches) is a tool: it lives beside the A/B baselines, not
+# beside the product library
+DEV_LIB = os.path.join(os.path.dirname(HERE), "tools", "ab_libs", "libqattn_dev.so")
+SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip", "qattn_attn_pv16.hip", "qattn_attn_w4.hip"]
 # (source, extra flags, object name): the two big kernel files are compiled once per operand format / head dimension so that
 # the build runs in parallel (the longest single translation unit sets the wall time)
 # (a unit with a define is compiled through a two-line wrapper file named after the unit, so that -save-temps leaves one .s
@@ -34,8 +37,9 @@ UNITS = [
     ("qattn_api.hip", [], "qattn_api"),
     ("qattn_probe.hip", [], "qattn_probe"),
     ("qattn_attn_pv16.hip", [], "qattn_attn_pv16"),
+    ("qattn_attn_w4.hip", [], "qattn_attn_w4"),
 ]
-# `--dev` builds libqattn_hip_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
+# `--dev` builds tools/ab_libs/libqattn_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
 # QATTN_* environment switches.  The product library contains none of them.
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",
@@ -60,7 +64,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
           extra_defines=()) -> str:
     """Compile what is stale and link the library; returns its path.  save_temps: compile every unit with -save-temps into
     BUILD_TEMPS instead (same flags, same code; the library is left alone) and return that directory.
-    variant / extra_defines (development): a library of its own, tools/bin/libqattn_<variant>.so, compiled with the given -D macros
+    variant / extra_defines (development): a library of its own, tools/ab_libs/libqattn_<variant>.so, compiled with the given -D macros
     (kernel tuning knobs) for A/B runs with tools/ab.py or tools/kstats.sh."""
     extra_defines = sorted(extra_defines)
     if save_temps and (variant or extra_defines or dev):
@@ -71,9 +75,11 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
     # the macros are part of the object directory's name: another set of -D values never reuses stale objects
     tag = ("_" + hashlib.sha1(" ".join(extra_defines).encode()).hexdigest()[:8]) if extra_defines else ""
     build_dir = BUILD_TEMPS if save_temps else BUILD + ("_dev" if dev else "") + (f"_var_{variant}{tag}" if variant else "")
-    lib = LIB.replace(".so", "_dev.so") if dev else LIB
+    lib = DEV_LIB if dev else LIB
+    if variant or dev:
+        os.makedirs(os.path.dirname(DEV_LIB), exist_ok=True)
     if variant:
-        lib = os.path.join(os.path.dirname(HERE), "tools", "bin", f"libqattn_{variant}.so")
+        lib = os.path.join(os.path.dirname(HERE), "tools", "ab_libs", f"libqattn_{variant}.so")
         os.makedirs(os.path.dirname(lib), exist_ok=True)
     os.makedirs(build_dir, exist_ok=True)
     hipcc = _hipcc()

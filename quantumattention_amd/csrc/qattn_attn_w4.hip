@@ -1,0 +1,896 @@
+// qattn_attn_w4.hip -- FP8 fused attention forward for gfx950 (MI355X / CDNA4): 4 waves x 64 query rows, one wave per SIMD.
+//
+// Replaces fwd_attend_ker<D,causal,..> + its launcher (src/quantum_attn/tk/attention.py:97-349, 355-647; the loop being replaced:
+// :228-322) behind the op quantum_attn::fp8_attention_forward (src/quantum_attn/ops.py:98-121) for the headline case -- D = 128,
+// head-wise scales, one e4m3 term of P (byte exponential), non-causal.  Same algorithm, numerics and K / V fragment images as the
+// 8-wave kernel (qattn_attn_v2.hip); what differs is how the work sits on a CU ("next round" item 1):
+//
+//  * workgroup = 4 waves = 256 query rows; a wave owns 64 rows = two 32-row tiles A and B, is alone on its SIMD and has the whole
+//    512-entry register file: O^T (128), Q^T (32) and the row-sum accumulators live where only the matrix pipe reads them, the
+//    score tiles S^T (2 x 64, ping-pong) and P (2 x 16) where the vector pipe works.
+//  * every K / V fragment read from LDS feeds TWO MFMAs (tile A, tile B): 16 ds_read_b128 per 64-key chunk and wave for 16 products
+//    (8 waves x 16 for 8 each in the 8-wave kernel: LDS reads per MFMA 1.74 -> 0.9).
+//  * one iteration = 18 hand-placed slots: PV(t-2) of both tiles (8 products), their row sums (4 short products), QK^T(t) of both
+//    tiles (8 products), with the softmax of chunk t-1 -- 16 groups of 4 scores and the two tiles' running maxima -- spread under
+//    them; operands are requested two slots ahead, the next iteration's first V fragments at the end.  Nothing in an iteration
+//    depends on a product of the same iteration: a lone wave keeps both pipes busy without a partner to hide its latencies.
+//  * K/V ring of 6 stages {K(t), V(t-1)} x 16 KiB filled by LDS-DMA, one stage (4 pieces per wave) per iteration, requested three
+//    iterations ahead from inside the slots; the waves meet every second iteration (s_waitcnt vmcnt(4) + s_barrier).
+//  * persistent: one workgroup per CU walks its query blocks.
+#include <type_traits>
+
+#include "qattn_attn.h"
+#include "qattn_w4_acc.inc"
+
+namespace qattn {
+
+constexpr int kW4Waves = 4;
+constexpr int kW4Rows = 64;                      // query rows per wave (two MFMA N tiles)
+constexpr int kW4D = 128;
+constexpr int kW4CH = 64 * kW4D;                 // bytes of one K (or V) chunk
+constexpr int kW4Stage = 2 * kW4CH;
+constexpr int kW4Lead = 3;                       // stage s is requested (global loads) during iteration s - 3, written to LDS during s - 2
+constexpr int kW4Stages = 5;                     // ring slots, see w4_sweep
+constexpr int kW4Ring = kW4Stages * kW4Stage;    // 80 KiB
+// the idle ring doubles as the rescue's scratch (four merge slots + the rescued rows' parked Q^T fragments), which is a little larger
+constexpr int kW4Area = kW4Ring > 4 * rescue_slot_bytes<kW4D>() + kW4Waves * ((kW4D / 64) << 11) ? kW4Ring : 4 * rescue_slot_bytes<kW4D>() + kW4Waves * ((kW4D / 64) << 11);
+// behind it: 8 vote words (one per 32-row group), 8 spare, then the head's V chunk scale words
+constexpr int kW4Lds = kW4Area + 64 + 4 * kVxWords;
+
+template <bool NEFF>
+struct W4State {
+    v16f o[2][4];        // O^T accumulators [tile][32-row block of D]
+    v16f s[2][2][2];     // S^T ping-pong [t & 1][tile][32-key tile]
+    v8i p[2][2];         // P^T (e4m3 bytes) ping-pong [t & 1][tile]
+    v8i qf[2][2];        // Q^T fragments [tile][k-step]
+    v8i vpre;            // V fragment (row block 0) of the NEXT iteration's PV
+    v4f lsum[2];         // row sums of the quantised P' (v_mfma_f32_16x16x128, see qattn_attn_v2.hip WaveState::lsum)
+    v4f lsq[2];          // ... and of its bytes read as e5m2 (effective key count)
+    v8i ones;
+    float m_run[2], m_true[2], mcv[2], lim[2];
+    float c;
+    int vsx;
+};
+
+constexpr float kW4U16 = 1.0f / 65535.0f;   // v_cvt_pknorm_u16_f32 maps [0, 1] to [0, 65535]
+
+// 4 scores -> the e4m3 bytes of 2^x (qattn_attn_v2.hip byte_group: 4 v_fma_f32, 2 v_cvt_pknorm_u16_f32, 1 v_perm_b32)
+__device__ __forceinline__ void w4_byte_group(const v16f& sx, int j, float c8, float off8, v8i& pv, int w) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const float a0 = __builtin_fmaf(sx[4 * j + 0], c8, off8), a1 = __builtin_fmaf(sx[4 * j + 1], c8, off8);
+    const float a2 = __builtin_fmaf(sx[4 * j + 2], c8, off8), a3 = __builtin_fmaf(sx[4 * j + 3], c8, off8);
+    const us2 qa = __builtin_amdgcn_cvt_pknorm_u16(a0, a1), qb = __builtin_amdgcn_cvt_pknorm_u16(a2, a3);
+    unsigned ua, ub;
+    __builtin_memcpy(&ua, &qa, 4);
+    __builtin_memcpy(&ub, &qb, 4);
+    unsigned b = __builtin_amdgcn_perm(ub, ua, 0x06040200u);
+    asm volatile("" : "+v"(b));   // stays in this slot
+    pv[w] = (int)b;
+}
+
+// the running maximum of a tile's 32 scores per lane in three interleaved v_max3 chains (qattn_attn.h max3_raw), two links per call:
+// K = 0 .. 7, then w4_max_finish.  The scores were written by MFMAs of the PREVIOUS iteration (>= 2 products ago): landed.
+template <int K>
+__device__ __forceinline__ void w4_max_pair(const v16f& s0, const v16f& s1, float& a, float& b, float& c) {
+#if defined(W4_ABL) && (W4_ABL & 4)
+    a = b = c = s0[0];
+    return;
+#endif
+    auto V = [&](int i) -> float { return i < 16 ? s0[i & 15] : s1[i & 15]; };
+    if constexpr (K == 0) { a = max3_raw(V(0), V(1), V(2)); b = max3_raw(V(3), V(4), V(5)); }
+    if constexpr (K == 1) { c = max3_raw(V(6), V(7), V(8)); a = max3_raw(a, V(9), V(10)); }
+    if constexpr (K == 2) { b = max3_raw(b, V(11), V(12)); c = max3_raw(c, V(13), V(14)); }
+    if constexpr (K == 3) { a = max3_raw(a, V(15), V(16)); b = max3_raw(b, V(17), V(18)); }
+    if constexpr (K == 4) { c = max3_raw(c, V(19), V(20)); a = max3_raw(a, V(21), V(22)); }
+    if constexpr (K == 5) { b = max3_raw(b, V(23), V(24)); c = max3_raw(c, V(25), V(26)); }
+    if constexpr (K == 6) { a = max3_raw(a, V(27), V(28)); b = max3_raw(b, V(29), V(30)); }
+    if constexpr (K == 7) { c = max3_raw(c, V(31), V(31)); }
+}
+template <bool TRACK>
+__device__ __forceinline__ float w4_max_finish(float a, float b, float c, float& m_true) {
+    float mx = max3_raw(a, b, c);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    if (TRACK) m_true = max3_raw(m_true, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    return max3_raw(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+}
+
+__device__ __forceinline__ float w4_byte_offset(float m, float c) {   // the additive constant of the byte formula for reference m
+    return __builtin_fmaf((-8.0f * kW4U16) * m, c, (8.0f * kPShiftByte + 56.0f + kByteBias) * kW4U16);
+}
+
+#ifdef W4_DBG_DRAIN   // debugging: every product has landed before anything else issues
+#define W4_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// ---- MFMAs through asm, with the register file each operand lives in spelled out.  Left to the compiler (ROCm 7.2, 512 registers per
+// lane) every accumulator of a kernel goes to one side of the unified file: with the score tiles in AccVGPRs the softmax paid 390
+// v_accvgpr moves per two iterations and the kernel spilled; the scores must sit where the vector pipe reads them ("v"), O^T, the row
+// sums and Q^T where only the matrix pipe does ("a").
+// HAZARDS the compiler cannot see (it does not know these statements are MFMAs; gfx950 does not interlock a vector instruction that
+// reads or overwrites an MFMA result in flight): every vector read of a score tile happens a whole iteration (>= 3 later MFMAs) after the
+// products that wrote it; the three places that touch accumulators otherwise -- the references' start after QK^T(0), the fix-up branch and
+// the epilogue -- sit behind w4_mfma_drain().
+__device__ __forceinline__ void w4_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// S = K.Q^T (first k-step: C = 0) and S += K.Q^T
+template <int FMT>
+__device__ __forceinline__ void w4_qk0(v16f& s, const v8i& k, const v8i& q) {
+    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, 0 cbsz:%3 blgp:%4" : "=&v"(s) : "v"(k), "a"(q), "n"(FMT), "n"(FMT));
+}
+template <int FMT>
+__device__ __forceinline__ void w4_qk1(v16f& s, const v8i& k, const v8i& q) {
+    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:%3 blgp:%4" : "+v"(s) : "v"(k), "a"(q), "n"(FMT), "n"(FMT));
+}
+// The accumulators are PINNED: O^T block (tile x, row block m) = a[16 (4 x + m) : + 15], lsum[x] = a[128 + 4 x : + 3], lsq[x] =
+// a[136 + 4 x : + 3].  The fix-up branch rescales single registers of them, which an asm operand cannot name (no sub-register
+// syntax): the text names them literally (qattn_w4_acc.inc, tools/gen_w4_asm.py).  Unpinned, the values the branch produced met the
+// loop's own at the back edge in other registers and the compiler rotated 16-register tuples through the loop body (300 v_accvgpr
+// moves per two iterations, some of them right behind a product whose result they read).
+#define W4_OREG_0 "{a[0:15]}"
+#define W4_OREG_1 "{a[16:31]}"
+#define W4_OREG_2 "{a[32:47]}"
+#define W4_OREG_3 "{a[48:63]}"
+#define W4_OREG_4 "{a[64:79]}"
+#define W4_OREG_5 "{a[80:95]}"
+#define W4_OREG_6 "{a[96:111]}"
+#define W4_OREG_7 "{a[112:127]}"
+#define W4_LSUM_0 "{a[128:131]}"
+#define W4_LSUM_1 "{a[132:135]}"
+#define W4_LSQ_0 "{a[136:139]}"
+#define W4_LSQ_1 "{a[140:143]}"
+// O^T += V^T.P^T into block B = 4 x + m; VS: V's chunk scale (E8M0 byte 0 of `sw`) and 2^0 for P (byte 1), qattn_attn.h mfma_pv
+template <int B, int V_FMT, bool VS>
+__device__ __forceinline__ void w4_pv(v16f& o, const v8i& v, const v8i& pb, int sw) {
+#define W4_PV_CASE(b)                                                                                                                       \
+    if constexpr (B == b) {                                                                                                                 \
+        if constexpr (VS)                                                                                                                   \
+            asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel:[0,1,0] op_sel_hi:[0,0,0] cbsz:%4"                  \
+                         : "+" W4_OREG_##b(o) : "v"(v), "v"(pb), "v"(sw), "n"(V_FMT));                                                      \
+        else                                                                                                                                \
+            asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:%3" : "+" W4_OREG_##b(o) : "v"(v), "v"(pb), "n"(V_FMT));           \
+    }
+    W4_PV_CASE(0) W4_PV_CASE(1) W4_PV_CASE(2) W4_PV_CASE(3) W4_PV_CASE(4) W4_PV_CASE(5) W4_PV_CASE(6) W4_PV_CASE(7)
+#undef W4_PV_CASE
+}
+// row sums of tile X's P bytes read as e4m3 (SQ = false: lsum) or e5m2 (SQ = true: lsq)
+template <int X, bool SQ>
+__device__ __forceinline__ void w4_rowsum(v4f& l, const v8i& ones, const v8i& pb) {
+    if constexpr (X == 0 && !SQ) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+" W4_LSUM_0(l) : "a"(ones), "v"(pb));
+    if constexpr (X == 1 && !SQ) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+" W4_LSUM_1(l) : "a"(ones), "v"(pb));
+    if constexpr (X == 0 && SQ) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0 blgp:1" : "+" W4_LSQ_0(l) : "a"(ones), "v"(pb));
+    if constexpr (X == 1 && SQ) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0 blgp:1" : "+" W4_LSQ_1(l) : "a"(ones), "v"(pb));
+}
+// a value that is to live in AccVGPRs from here on (the copy happens once, here)
+template <typename T>
+__device__ __forceinline__ void w4_to_acc(T& x) {
+    T y;
+    asm volatile("; %0 -> acc" : "=a"(y) : "0"(x));
+    x = y;
+}
+
+// One pipelined iteration (1 <= t <= n): PV(t-2) and the row sums of P(t-2), QK^T(t), softmax(t-1), for both tiles.  PAR = t & 1.
+//   kbuf  : stage(t), K part (+ lane offset)       vprev : stage(t-1), V part = V(t-2)       vnext : stage(t), V part = V(t-1)
+//   dma(i): moves piece i (0 .. 3) of the stages this iteration is responsible for (w4_sweep: store of stage t + 2, load of stage t + 3)
+// A fragment is read two slots (128 matrix-pipe cycles) before the first of the two products it feeds; st.vpre holds row block 0 of
+// V(t-2), read at the end of the previous iteration.
+// FINAL (the peeled last step of a sweep with an odd number of chunks): no QK^T.  It must not issue one "for nobody", as the 8-wave
+// kernel does: a score tile that no later instruction reads is a dead value to the compiler, which hands its registers to values
+// defined a few slots later -- and the product's result lands on top of them 64 cycles after its issue (found on the GPU: the last
+// chunk of every row lost most of its weights).
+// Slot order: PV row blocks 0, 1 | QK^T | PV row blocks 2, 3 | row sums.  The products that END an iteration write pinned AccVGPRs; the
+// score tiles are complete six products before: whatever the compiler puts at a loop exit or a join (it re-homes values there, with
+// plain moves it does not pad) reads scores that have landed, and no late result falls on a register it has given away.
+template <int QK_FMT, int V_FMT, int PAR, bool VS, bool NEFF, bool TRACK, bool FINAL, typename Dma>
+__device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* kbuf, const unsigned char* vprev, const unsigned char* vnext,
+                                        const unsigned* vx_next, Dma&& dma) {
+    const v16f (&sc)[2][2] = st.s[PAR ^ 1];   // S(t-1): being exponentiated
+    v16f (&sn)[2][2] = st.s[PAR];             // S(t)
+    v8i (&pc)[2] = st.p[PAR ^ 1];             // P(t-1): being produced
+    const v8i (&pp)[2] = st.p[PAR];           // P(t-2): consumed by PV
+    const float cx = (8.0f * kW4U16) * st.c;
+    const float mcA = st.mcv[0], mcB = st.mcv[1];
+    float aA, bA, cA, aB, bB, cB;
+    v8i ka, kb, kc, kd;
+#ifndef W4_ABL
+#define W4_ABL 0   // timing-only ablations (results wrong): 1 = no stage requests inside the steps, 2 = no exponentials, 4 = no running maxima
+#endif
+#define W4_GROUP(X, G, MC) do { if (!(W4_ABL & 2)) w4_byte_group(sc[X][(G) >> 2], (G)&3, cx, MC, pc[X], G); } while (0)
+    // slot 0
+    w4_pv<0, V_FMT, VS>(st.o[0][0], st.vpre, pp[0], st.vsx);
+    W4_FENCE();
+    const v8i v1 = lds_read_frag(vprev + (1 << 11));
+    W4_GROUP(0, 0, mcA);
+    w4_max_pair<0>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 1
+    w4_pv<4, V_FMT, VS>(st.o[1][0], st.vpre, pp[1], st.vsx);
+    W4_FENCE();
+    W4_GROUP(0, 1, mcA);
+    w4_max_pair<1>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 2
+    w4_pv<1, V_FMT, VS>(st.o[0][1], v1, pp[0], st.vsx);
+    W4_FENCE();
+    if constexpr (!FINAL) ka = lds_read_frag(kbuf + (0 << 11));   // K(tile 0, k-step 0)
+    W4_GROUP(0, 2, mcA);
+    w4_max_pair<2>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 3
+    w4_pv<5, V_FMT, VS>(st.o[1][1], v1, pp[1], st.vsx);
+    W4_FENCE();
+    W4_GROUP(0, 3, mcA);
+    w4_max_pair<3>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 4: S(t) = K.Q^T, both tiles per K fragment
+    if constexpr (!FINAL) w4_qk0<QK_FMT>(sn[0][0], ka, st.qf[0][0]);
+    W4_FENCE();
+    if constexpr (!FINAL) kb = lds_read_frag(kbuf + (2 << 11));   // K(tile 1, k-step 0)
+    W4_GROUP(0, 4, mcA);
+    w4_max_pair<4>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 5
+    if constexpr (!FINAL) w4_qk0<QK_FMT>(sn[1][0], ka, st.qf[1][0]);
+    W4_FENCE();
+    W4_GROUP(0, 5, mcA);
+    w4_max_pair<5>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 6
+    if constexpr (!FINAL) w4_qk0<QK_FMT>(sn[0][1], kb, st.qf[0][0]);
+    W4_FENCE();
+    if constexpr (!FINAL) kc = lds_read_frag(kbuf + (1 << 11));   // K(tile 0, k-step 1)
+    W4_GROUP(0, 6, mcA);
+    w4_max_pair<6>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 7
+    if constexpr (!FINAL) w4_qk0<QK_FMT>(sn[1][1], kb, st.qf[1][0]);
+    W4_FENCE();
+    W4_GROUP(0, 7, mcA);
+    w4_max_pair<7>(sc[0][0], sc[0][1], aA, bA, cA);
+    W4_FENCE();
+    // slot 8
+    if constexpr (!FINAL) w4_qk1<QK_FMT>(sn[0][0], kc, st.qf[0][1]);
+    W4_FENCE();
+    if constexpr (!FINAL) kd = lds_read_frag(kbuf + (3 << 11));   // K(tile 1, k-step 1)
+    W4_GROUP(1, 0, mcB);
+    w4_max_pair<0>(sc[1][0], sc[1][1], aB, bB, cB);
+    const float mxA = w4_max_finish<TRACK>(aA, bA, cA, st.m_true[0]);
+    W4_FENCE();
+    // slot 9
+    if constexpr (!FINAL) w4_qk1<QK_FMT>(sn[1][0], kc, st.qf[1][1]);
+    W4_FENCE();
+    dma(0);
+    W4_GROUP(1, 1, mcB);
+    w4_max_pair<1>(sc[1][0], sc[1][1], aB, bB, cB);
+    W4_FENCE();
+    // slot 10
+    if constexpr (!FINAL) w4_qk1<QK_FMT>(sn[0][1], kd, st.qf[0][1]);
+    W4_FENCE();
+    const v8i v2 = lds_read_frag(vprev + (2 << 11));
+    W4_GROUP(1, 2, mcB);
+    w4_max_pair<2>(sc[1][0], sc[1][1], aB, bB, cB);
+    W4_FENCE();
+    // slot 11
+    if constexpr (!FINAL) w4_qk1<QK_FMT>(sn[1][1], kd, st.qf[1][1]);
+    W4_FENCE();
+    dma(1);
+    W4_GROUP(1, 3, mcB);
+    w4_max_pair<3>(sc[1][0], sc[1][1], aB, bB, cB);
+    W4_FENCE();
+    // slot 12
+    w4_pv<2, V_FMT, VS>(st.o[0][2], v2, pp[0], st.vsx);
+    W4_FENCE();
+    const v8i v3 = lds_read_frag(vprev + (3 << 11));
+    W4_GROUP(1, 4, mcB);
+    w4_max_pair<4>(sc[1][0], sc[1][1], aB, bB, cB);
+    W4_FENCE();
+    // slot 13
+    w4_pv<6, V_FMT, VS>(st.o[1][2], v2, pp[1], st.vsx);
+    W4_FENCE();
+    dma(2);
+    W4_GROUP(1, 5, mcB);
+    w4_max_pair<5>(sc[1][0], sc[1][1], aB, bB, cB);
+    W4_FENCE();
+    // slot 14
+    w4_pv<3, V_FMT, VS>(st.o[0][3], v3, pp[0], st.vsx);
+    W4_FENCE();
+    const v8i vnx = lds_read_frag(vnext + (0 << 11));   // row block 0 of the NEXT iteration's V
+    int vsn = st.vsx;
+    if (VS) vsn = (int)*vx_next;                        // ... and its scale byte
+    W4_GROUP(1, 6, mcB);
+    w4_max_pair<6>(sc[1][0], sc[1][1], aB, bB, cB);
+    W4_FENCE();
+    // slot 15
+    w4_pv<7, V_FMT, VS>(st.o[1][3], v3, pp[1], st.vsx);
+    W4_FENCE();
+    dma(3);
+    W4_GROUP(1, 7, mcB);
+    w4_max_pair<7>(sc[1][0], sc[1][1], aB, bB, cB);
+    W4_FENCE();
+    // slot 16: row sums of P(t-2), tile A
+    w4_rowsum<0, false>(st.lsum[0], st.ones, pp[0]);
+    if (NEFF) w4_rowsum<0, true>(st.lsq[0], st.ones, pp[0]);
+    W4_FENCE();
+    const float mxB = w4_max_finish<TRACK>(aB, bB, cB, st.m_true[1]);
+    W4_FENCE();
+    // slot 17: ... tile B
+    w4_rowsum<1, false>(st.lsum[1], st.ones, pp[1]);
+    if (NEFF) w4_rowsum<1, true>(st.lsq[1], st.ones, pp[1]);
+    W4_FENCE();
+    st.vpre = vnx;
+    st.vsx = vsn;
+    const bool growA = mxA > st.lim[0], growB = mxB > st.lim[1];
+    W4_FENCE();
+    // rare fix-up, per tile and with the 8-wave kernel's own expressions (a tile's bits do not depend on its neighbour): some row's
+    // maximum grew beyond the deferred-rescale threshold -- rescale what has been accumulated (O and the row sums include chunk t-2)
+    // and redo this chunk's bytes against the new reference
+    if (__builtin_expect(__any(growA || growB) != 0, 0)) {
+        w4_mfma_drain();   // the accumulators read and rewritten below are at rest
+        auto fix = [&](auto x_tag, float mx, bool grow) {
+            constexpr int X = decltype(x_tag)::value;
+            if (!__any(grow)) return;
+            const float c = st.c;
+            const float m_new = fmaxf(st.m_run[X], mx);
+            const float alpha = __builtin_amdgcn_exp2f((st.m_run[X] - m_new) * c);
+            const float alpha16 = __uint_as_float(swizzle_xor16(__float_as_uint(alpha)));   // lane n < 16: queries n and n + 16
+            float t0, t1, t2, t3;
+            if constexpr (X == 0)
+                asm volatile(W4_SCALE_O0_TEXT
+                             : "+" W4_OREG_0(st.o[0][0]), "+" W4_OREG_1(st.o[0][1]), "+" W4_OREG_2(st.o[0][2]), "+" W4_OREG_3(st.o[0][3]), "+" W4_LSUM_0(st.lsum[0]),
+                               "+" W4_LSQ_0(st.lsq[0]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                             : [al] "v"(alpha), [al16] "v"(alpha16), [al2] "v"(alpha * alpha), [al162] "v"(alpha16 * alpha16));
+            else
+                asm volatile(W4_SCALE_O1_TEXT
+                             : "+" W4_OREG_4(st.o[1][0]), "+" W4_OREG_5(st.o[1][1]), "+" W4_OREG_6(st.o[1][2]), "+" W4_OREG_7(st.o[1][3]), "+" W4_LSUM_1(st.lsum[1]),
+                               "+" W4_LSQ_1(st.lsq[1]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                             : [al] "v"(alpha), [al16] "v"(alpha16), [al2] "v"(alpha * alpha), [al162] "v"(alpha16 * alpha16));
+            st.m_run[X] = m_new;
+            const float mc2 = w4_byte_offset(m_new, c);
+            st.mcv[X] = mc2;
+            st.lim[X] = m_new + kRescaleThrByte / c;
+#pragma unroll
+            for (int g = 0; g < 8; g++) W4_GROUP(X, g, mc2);
+        };
+        fix(std::integral_constant<int, 0>{}, mxA, growA);
+        fix(std::integral_constant<int, 1>{}, mxB, growB);
+    }
+#undef W4_GROUP
+}
+
+// The KV sweep of one wave over n chunks (non-causal: every wave sees them all).  On return st.o / lsum / lsq / m_run / m_true are final.
+//
+// Ring protocol.  stage(s) = {K(s), V(s-1)} lives in slot s % kW4Stages; iteration t reads K(t) and (for the next iteration's first
+// products) V(t-1) from stage t, V(t-2) from stage t-1.  The first three stages of a block come by LDS-DMA (w4_block, with the block's
+// other loads).  Inside the sweep a stage travels THROUGH REGISTERS: a lone wave pays every LDS-DMA request with ~60 issue cycles that
+// nothing covers (the C2 launch ran 14 % faster without the four requests per iteration, profiles/r05/ab_w4_ablations.log), a
+// global_load_dwordx4 + ds_write_b128 pair costs a third of that.  Iteration t: piece i (slots 9, 11, 13, 15) of stage t + 2, loaded
+// during iteration t - 1 into four pinned AccVGPRs, is written to LDS (s_waitcnt vmcnt(3): three younger loads may be in flight), and
+// the same registers take the load of piece i of stage t + 3.  The waves meet at the top of every EVEN iteration (s_waitcnt
+// lgkmcnt(0) + s_barrier): the stores of iterations t - 2 and t - 1 -- stages t and t + 1, which the next two iterations read -- are
+// complete.  The slot stage s + kW4Stages overwrites is written in iteration s + 3, behind the barrier of iteration s + 2 or s + 3,
+// by which every wave has left iteration s + 1, the last reader of stage s.
+#define W4_STG_0 "{a[200:203]}"
+#define W4_STG_1 "{a[204:207]}"
+#define W4_STG_2 "{a[208:211]}"
+#define W4_STG_3 "{a[212:215]}"
+struct W4Staging { v4i r[4]; };
+template <int I>
+__device__ __forceinline__ void w4_stage_load(W4Staging& g, unsigned off, const unsigned char* base) {
+#define W4_LD(i) if constexpr (I == i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=" W4_STG_##i(g.r[i]) : "v"(off), "s"(base) : "memory");
+    W4_LD(0) W4_LD(1) W4_LD(2) W4_LD(3)
+#undef W4_LD
+}
+template <int I, int OFF>
+__device__ __forceinline__ void w4_stage_store(const W4Staging& g, unsigned lds_addr) {
+#define W4_ST(i) if constexpr (I == i) asm volatile("s_waitcnt vmcnt(3)\n\tds_write_b128 %0, %1 offset:%2" ::"v"(lds_addr), W4_STG_##i(g.r[i]), "n"(OFF) : "memory");
+    W4_ST(0) W4_ST(1) W4_ST(2) W4_ST(3)
+#undef W4_ST
+}
+template <int QK_FMT, int V_FMT, bool VS, bool NEFF, bool TRACK>
+__device__ __forceinline__ void w4_sweep(W4State<NEFF>& st, const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
+                                         int n, int q0, int wave, int lane, const unsigned* vx) {
+    constexpr int CH = kW4CH, STAGE = kW4Stage;
+    const int hh = lane >> 5;
+    const int frag_lane_off = (hh << 10) + ((lane & 31) << 4);
+    // ---- stage traffic: strictly in order, four 1 KiB pieces per stage and wave (K pieces w, w + 4; V pieces w, w + 4); source and
+    // destination offsets advance incrementally (qattn_attn_v2.hip kv_sweep)
+    const unsigned koff_max = (unsigned)(p.nchunks - 1) * CH;
+    // the caller has requested stages 0 .. 2 by LDS-DMA: the loads start at stage 3 = {K(3), V(2)}, the stores at ring slot 3
+    unsigned koff = min(3u * CH, koff_max), voff = min(2u * CH, koff_max), lds_w = 3 * STAGE;
+    const unsigned lane_piece = ((unsigned)wave << 10) + ((unsigned)lane << 4);
+    const unsigned lds_lane = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + lane_piece;
+    W4Staging stg;
+    auto stage_load = [&](auto i_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_tag)::value;
+        const unsigned off = (I < 2 ? koff : voff) + lane_piece + ((I & 1) ? 4096u : 0u);
+        w4_stage_load<I>(stg, off, I < 2 ? kg : vg);
+        if constexpr (I == 3) {
+            voff = koff;
+            koff = min(koff + (unsigned)CH, koff_max);
+        }
+    };
+    auto stage_store = [&](auto i_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_tag)::value;
+        w4_stage_store<I, (I < 2 ? 0 : CH) + ((I & 1) ? 4096 : 0)>(stg, lds_lane + lds_w);
+        if constexpr (I == 3) lds_w = lds_w + STAGE == kW4Ring ? 0u : lds_w + STAGE;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto stage_piece = [&](int i) __attribute__((always_inline)) {   // (i is a literal at every call site)
+        if (i == 0) { stage_store(I0{}); stage_load(I0{}); }
+        if (i == 1) { stage_store(I1{}); stage_load(I1{}); }
+        if (i == 2) { stage_store(I2{}); stage_load(I2{}); }
+        if (i == 3) { stage_store(I3{}); stage_load(I3{}); }
+    };
+    unsigned slot_cur = 0, slot_prev = 0;
+    auto sync_top = [&](int t) __attribute__((always_inline)) {   // top of iteration t
+#ifdef W4_DBG_SYNC_ALL   // debugging: every iteration waits for everything and meets the other waves
+        if (true) {
+#else
+        if ((t & 1) == 0) {
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stores of the last two iterations
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_nop 0" ::: "memory");   // keeps the iterations of a pair separate scheduling regions
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        slot_prev = slot_cur;
+        slot_cur = slot_cur + STAGE == kW4Ring ? 0u : slot_cur + STAGE;
+    };
+    const unsigned* vx_next = vx;
+    const int vx_step = (VS && p.vexp != nullptr) ? 4 : 0;
+
+    {   // A of the row-sum MFMA: lane = row (l & 15) + 16 * k-group; rows 0 / 1 are 1.0 (e4m3 0x38) on even / odd k-groups
+        const int row = lane & 15, kgrp = lane >> 4;
+        const int one = ((row == 0 && !(kgrp & 1)) || (row == 1 && (kgrp & 1))) ? 0x38383838 : 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) st.ones[w] = one;
+        w4_to_acc(st.ones);
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) { st.p[0][0][w] = 0; st.p[0][1][w] = 0; st.p[1][0][w] = 0; st.p[1][1][w] = 0; }
+
+    // ---- t = 0: QK^T(0) only; the rows' references start at chunk 0's maxima (qattn_attn_v2.hip kv_sweep)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the block's first three stages (LDS-DMA, w4_block)
+        sync_top(0);
+        const unsigned char* kbuf = smem + slot_cur + frag_lane_off;
+        {
+            const v8i ka = lds_read_frag(kbuf + (0 << 11)), kb = lds_read_frag(kbuf + (2 << 11));
+            w4_qk0<QK_FMT>(st.s[0][0][0], ka, st.qf[0][0]);
+            w4_qk0<QK_FMT>(st.s[0][1][0], ka, st.qf[1][0]);
+            w4_qk0<QK_FMT>(st.s[0][0][1], kb, st.qf[0][0]);
+            w4_qk0<QK_FMT>(st.s[0][1][1], kb, st.qf[1][0]);
+            const v8i kc = lds_read_frag(kbuf + (1 << 11)), kd = lds_read_frag(kbuf + (3 << 11));
+            w4_qk1<QK_FMT>(st.s[0][0][0], kc, st.qf[0][1]);
+            w4_qk1<QK_FMT>(st.s[0][1][0], kc, st.qf[1][1]);
+            w4_qk1<QK_FMT>(st.s[0][0][1], kd, st.qf[0][1]);
+            w4_qk1<QK_FMT>(st.s[0][1][1], kd, st.qf[1][1]);
+        }
+        st.vpre = lds_read_frag(kbuf + CH + (0 << 11));   // stage(0)'s V part (= V(0), multiplied by P = 0 at t = 1)
+        stage_load(I0{}); stage_load(I1{}); stage_load(I2{}); stage_load(I3{});   // stage 3 (stored by iteration 1)
+        advance();
+        w4_mfma_drain();   // the score tiles are read right away
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            prep_scores<false, false, true>(st.s[0][x][0], st.s[0][x][1], p, 0, q0 + 32 * x, q0 + 32 * x + (lane & 31), hh, nullptr);
+            float mx0 = max32_after_mfma(st.s[0][x][0], st.s[0][x][1]);
+            const auto sw0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx0), __float_as_uint(mx0), false, false);
+            mx0 = fmaxf(__uint_as_float(sw0[0]), __uint_as_float(sw0[1]));
+            const float m_new = fmaxf(st.m_run[x], mx0);
+            st.m_run[x] = m_new;
+            st.mcv[x] = w4_byte_offset(m_new, st.c);
+            st.lim[x] = m_new + kRescaleThrByte / st.c;
+        }
+    }
+    // ---- t = 1 .. n: full steps, two per trip (parity 1, then 0), ONE copy of the pair for the whole sweep: between two copies of a
+    // step the compiler re-homes the score tiles with moves it does not pad (they read a tile right behind the product that wrote it).
+    // Only the head's last chunk can reach past the key range; it is exponentiated by step n: the pair's second step (n even) or the
+    // peeled step (n odd), behind a wave-uniform test.  With n even the pair's second step issues a QK^T on whatever stage n holds
+    // (the clamped requests re-read the last chunk), for nobody.
+    auto full = [&](auto par_tag, int t, auto final_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool FINAL = decltype(final_tag)::value;
+        sync_top(t);
+        const unsigned char* kbuf = smem + slot_cur + frag_lane_off;
+        const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
+        advance();
+        // (every iteration moves a stage: beyond stage n the clamped source re-reads the head's last chunk into a slot nobody reads again;
+        // a branch inside the step would split it into basic blocks)
+        w4_step<QK_FMT, V_FMT, PAR, VS, NEFF, TRACK, FINAL>(st, kbuf, vprev, kbuf + CH, vx_next, [&](int i) __attribute__((always_inline)) { if (!(W4_ABL & 1)) stage_piece(i); });
+        if constexpr (VS) vx_next = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(vx_next) + vx_step);
+    };
+    // keys at or beyond Skv -> -inf, without compares: the test code sits inside the sweep's only loop, and 64 compare masks in scalar
+    // register pairs made the loop spill its scalars (130 v_readlane / v_writelane per trip).  x = (Skv - key) - 1/2 is positive for a
+    // live key and negative for a dead one, x * inf = +-inf, min(score, +-inf) keeps the score or makes it -inf: the 8-wave kernel's
+    // prep_scores result, bit for bit.  Register r of key tile kt holds key k0 + 32 kt + (r & 3) + 8 (r >> 2) + 4 hh.
+    auto mask_chunk = [&](auto par_tag, int chunk) __attribute__((always_inline)) {   // S(chunk) in st.s[PAR]
+        constexpr int PAR = decltype(par_tag)::value;
+        const float left = (float)(p.Skv - chunk * 64 - 4 * hh) - 0.5f;   // (exact: small integers)
+        float inf = __builtin_inff();
+        asm volatile("" : "+v"(inf));
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float xr = left - (float)(32 * kt + (r & 3) + 8 * (r >> 2));
+                    st.s[PAR][x][kt][r] = __builtin_fminf(st.s[PAR][x][kt][r], xr * inf);
+                }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using No = std::integral_constant<bool, false>;
+    // The sweep runs an EVEN number of steps, n2 = n rounded up: with n odd the extra chunk n lies wholly beyond the key range, is masked
+    // to -inf like a ragged tail (P = 0: no weight, no row sum) and multiplies whatever the clamped requests put into its stage.  One
+    // extra iteration for odd n instead of a peeled copy of the step, which the compiler surrounds with unpadded moves of the pinned
+    // accumulators.  Only the last pair can hold chunks that reach past the key range (wave-uniform tests).
+    const int n2 = (n + 1) & ~1;
+    const bool mask0 = (n2 - 1) * 64 > p.Skv, mask1 = n2 * 64 > p.Skv;   // chunks n2 - 2 and n2 - 1
+    int t = 1;
+    for (; t + 1 <= n2; t += 2) {
+        if (mask0 && t + 1 == n2) mask_chunk(P0{}, n2 - 2);
+        full(P1{}, t, No{});
+        if (mask1 && t + 1 == n2) mask_chunk(P1{}, n2 - 1);
+        full(P0{}, t + 1, No{});
+    }
+    // ---- t = n2 + 1 (odd): the last chunk's PV (V(n2 - 1) lives in stage(n2); its row block 0 is already in vpre)
+    {
+        sync_top(t);
+        const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
+        const v8i v1 = lds_read_frag(vprev + (1 << 11)), v2 = lds_read_frag(vprev + (2 << 11)), v3 = lds_read_frag(vprev + (3 << 11));
+        auto tail = [&](auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            const v8i& pa = st.p[PAR][0];
+            const v8i& pb = st.p[PAR][1];
+            w4_pv<0, V_FMT, VS>(st.o[0][0], st.vpre, pa, st.vsx);
+            w4_pv<4, V_FMT, VS>(st.o[1][0], st.vpre, pb, st.vsx);
+            w4_pv<1, V_FMT, VS>(st.o[0][1], v1, pa, st.vsx);
+            w4_pv<5, V_FMT, VS>(st.o[1][1], v1, pb, st.vsx);
+            w4_pv<2, V_FMT, VS>(st.o[0][2], v2, pa, st.vsx);
+            w4_pv<6, V_FMT, VS>(st.o[1][2], v2, pb, st.vsx);
+            w4_pv<3, V_FMT, VS>(st.o[0][3], v3, pa, st.vsx);
+            w4_pv<7, V_FMT, VS>(st.o[1][3], v3, pb, st.vsx);
+            w4_rowsum<0, false>(st.lsum[0], st.ones, pa);
+            w4_rowsum<1, false>(st.lsum[1], st.ones, pb);
+            if (NEFF) { w4_rowsum<0, true>(st.lsq[0], st.ones, pa); w4_rowsum<1, true>(st.lsq[1], st.ones, pb); }
+        };
+        tail(P1{});
+        // the last iteration's loads land in the pinned staging registers: wait for them while those still belong to this loop
+        asm volatile("s_waitcnt vmcnt(0)" ::W4_STG_0(stg.r[0]), W4_STG_1(stg.r[1]), W4_STG_2(stg.r[2]), W4_STG_3(stg.r[3]) : "memory");
+        w4_mfma_drain();   // the caller reads the accumulators
+    }
+}
+
+// The e-th set bit of m (qattn_attn_v2.hip select_bit)
+__device__ __forceinline__ int w4_select_bit(unsigned m, int e) {
+    int pos = 0;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 1)
+        if (__builtin_popcount(m & ((1u << (pos + step)) - 1u)) <= e) pos += step;
+    return pos;
+}
+
+// The flagged rows of a block (bits of the eight vote words, one word per 32-row group), gathered into dense groups of 32 and recomputed
+// with exact exponentials and two-term P, the key range split over the four waves (qattn_attn.h rescue_rows_at; the 8-wave kernel's
+// rescue_pass, qattn_attn_v2.hip, with this kernel's LDS layout).  Every wave is past the block's vote barrier: the ring is idle.
+template <int QK_FMT, int V_FMT, bool Q16>
+__device__ __forceinline__ void w4_rescue(const AttnParams& p, unsigned char* smem, int tid, int bid, int nrows) {
+    constexpr int D = kW4D, CH = kW4CH, NW = kW4Waves;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+    int head, qb;
+    map_block(p, bid, p.nqb, false, head, qb);
+    const int b = head / p.Hq, h = head % p.Hq;
+    const long bh = (long)b * p.Hq + h;
+    const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+    const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
+    const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
+    unsigned* vx = reinterpret_cast<unsigned*>(smem + kW4Area) + 16;   // (filled by the block's prologue, still valid)
+    float c, scale_q16 = 1.0f;
+    if (Q16) {
+        const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
+        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane) & 0x7fffffffu), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        c = p.sm_log2e * scale_q16 * p.sk[kv_head];
+    } else {
+        c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
+    }
+    unsigned masks[8];
+    {
+        const volatile unsigned* vote = reinterpret_cast<const volatile unsigned*>(smem + kW4Area);
+        v4i va, vb;
+        lds_read_8words_raw(vote, va, vb);
+#pragma unroll
+        for (int w = 0; w < 8; w++) masks[w] = (unsigned)(w < 4 ? va[w & 3] : vb[w & 3]);
+    }
+    // the rescued rows' Q^T fragments are parked in this lane's own LDS slots behind the merge area (4 slots of rescue_slot_bytes)
+    unsigned char* qslot = smem + 4 * rescue_slot_bytes<D>() + wave * ((D / 64) << 11) + (hh << 10) + (ql << 4);
+    static_assert(4 * rescue_slot_bytes<kW4D>() + kW4Waves * ((kW4D / 64) << 11) <= kW4Area, "the rescue's scratch fits the idle ring area");
+    for (int g0 = 0; g0 < nrows; g0 += 32) {
+        const bool have = g0 + ql < nrows;
+        int e = have ? g0 + ql : g0, wsel = 0;
+        unsigned msel = masks[0];
+#pragma unroll
+        for (int w = 0; w < 7; w++) {   // walk to the group that holds entry e
+            const int cnt = __builtin_popcount(masks[w]);
+            const bool next = wsel == w && e >= cnt;
+            e = next ? e - cnt : e;
+            msel = next ? masks[w + 1] : msel;
+            wsel = next ? w + 1 : wsel;
+        }
+        const int row = qb * kQPerWG + wsel * 32 + w4_select_bit(msel, e);
+        const int row_lo = __builtin_amdgcn_readfirstlane(row);
+        const int row_hi = __builtin_amdgcn_readlane(row, min(nrows - g0, 32) - 1);
+        const bool qvalid = row < p.Sq;
+#pragma unroll
+        for (int s_ = 0; s_ < D / 64; s_++) {
+            v8i f;
+            if (Q16) {
+                const float rinv = 1.0f / scale_q16;
+                const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? row : 0)) * D + hh * 32) * 2) + s_ * 8;
+                int2 w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint4 raw = qp[i];
+                    if (!qvalid) raw = make_uint4(0, 0, 0, 0);
+                    w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw, scale_q16, rinv);
+                }
+                f = v8i{w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y, w[3].x, w[3].y};
+            } else {
+                const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? row : 0)) * D) + hh * 32 + s_ * 64;
+                v4i lo = *reinterpret_cast<const v4i*>(qp), hi = *reinterpret_cast<const v4i*>(qp + 16);
+                if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
+                f = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            *reinterpret_cast<v4i*>(qslot + (s_ << 11)) = v4i{f[0], f[1], f[2], f[3]};
+            *reinterpret_cast<v4i*>(qslot + (s_ << 11) + 512) = v4i{f[4], f[5], f[6], f[7]};
+        }
+        rescue_rows_at<D, NW, QK_FMT, V_FMT, false, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
+                                                                       [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, Q16 ? vx : nullptr);
+    }
+}
+
+// One 256-row query block.  Returns the number of its rows left to w4_rescue (CHECK only; their vote words are in LDS).
+template <int QK_FMT, int V_FMT, bool Q16, bool CHECK>
+__device__ __forceinline__ int w4_block(const AttnParams& p, unsigned char* smem, int tid, int bid) {
+    constexpr int D = kW4D, CH = kW4CH, STAGE = kW4Stage, KS = 2, MB = 4;
+    constexpr bool VS = Q16, NEFF = CHECK;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+    int head, qb;
+    map_block(p, bid, p.nqb, false, head, qb);
+    const int b = head / p.Hq, h = head % p.Hq;
+    const long bh = (long)b * p.Hq + h;
+    const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+    const int q0_wg = qb * kQPerWG;
+    const int q0 = q0_wg + wave * kW4Rows;
+    const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
+    const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
+    const int n = p.nchunks;
+    unsigned* vote = reinterpret_cast<unsigned*>(smem + kW4Area);
+    unsigned* vx = vote + 16;
+
+    // AUTO: a block whose rows are predicted peaked (the pre-pass's score moments: qattn_attn.h many_rows_peaked) skips the one-term
+    // sweep; all its rows go to the rescue
+    if (CHECK) {
+        float var = 1.0f;
+        if (p.ssq_q) {
+            const int kvh = (head / p.Hq) * p.Hkv + (head % p.Hq) / (p.Hq / p.Hkv);
+            float sa, sb;
+            sum_partials_pair(p.ssq_q + (long)head * p.ssq_stride, p.ssq_k + (long)kvh * p.ssq_stride, p.ssq_n, lane, sa, sb);
+            var = sa * sb * p.var_mul;
+            if (!(var >= kVarDeadband)) var = 1.0f;
+        }
+        const bool wide = var >= kVarDeadband;
+        const bool start_two = predicted_r((float)p.Skv, 1.0f, p.peak_z) < kPeakR0 || (wide && many_rows_peaked((float)p.Skv, var));
+        if (__builtin_amdgcn_readfirstlane(start_two ? 1 : 0) != 0) {
+            if (Q16) {   // the V chunk scale words the rescue reads, and the head's scale (the block that holds row 0 writes it)
+                const unsigned vxw = (p.vexp && tid < n) ? p.vexp[kv_head * p.vexp_stride + tid] : 127u;
+                vx[tid] = (unsigned)vscale_word(vxw);
+                if (q0_wg == 0 && tid == 0) {
+                    const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
+                    unsigned am = 0u;
+                    for (int i = 0; i < p.amax_n; i++) am = max(am, p.q_amax_part[bh * p.amax_stride + i] & 0x7fffffffu);
+                    p.sq_out[bh] = make_scale(__uint_as_float(am), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+                }
+            }
+            const int valid = min(kQPerWG, p.Sq - q0_wg);
+            if (tid < 8) {
+                const int nv = min(32, max(0, valid - 32 * tid));
+                lds_write_word_raw(vote + tid, nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u));
+            }
+            lds_barrier();
+            return valid;
+        }
+    }
+
+    // ---- everything the head of a block needs from memory, requested at once: the ring's first stages, the V scale word of this
+    // thread, the head's abs-max words, the wave's Q rows (qattn_attn_v2.hip block_pass)
+    {
+        const unsigned koff_max = (unsigned)(n - 1) * CH;
+        unsigned koff = 0, voff = 0;
+        const unsigned lane16 = (unsigned)lane << 4;
+#pragma unroll
+        for (int s = 0; s < kW4Lead; s++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned pc = ((unsigned)wave << 10) + ((i & 1) ? 4096u : 0u);
+                if (i < 2)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg + (koff + pc + lane16)),
+                                                     (__attribute__((address_space(3))) void*)(smem + s * STAGE + pc), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg + (voff + pc + lane16)),
+                                                     (__attribute__((address_space(3))) void*)(smem + s * STAGE + CH + pc), 16, 0, 0);
+            }
+            voff = koff;
+            koff = min(koff + (unsigned)CH, koff_max);
+        }
+    }
+    W4State<NEFF> st;
+    float scale_q16 = 1.0f;
+    if (Q16) {
+        const unsigned* part = p.q_amax_part + bh * p.amax_stride;
+        const unsigned* vrow = p.vexp ? p.vexp + kv_head * p.vexp_stride : part;
+        const int vmax = p.vexp ? n - 1 : 0, amax_last = p.amax_n - 1;
+        static_assert(kVxWords == kW4Waves * 64, "one V scale word per thread");
+        unsigned vxw = vrow[min(tid, vmax)];
+        const unsigned a0 = part[min(lane, amax_last)], a1 = part[min(lane + 64, amax_last)];
+        const unsigned a2 = part[min(lane + 128, amax_last)], a3 = part[min(lane + 192, amax_last)];
+        uint4 rawq[2][KS][4];
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            const int qrow = q0 + 32 * x + ql;
+            const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qrow < p.Sq ? qrow : 0)) * D + hh * 32) * 2);
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) rawq[x][s][i] = qp[s * 8 + i];
+        }
+        asm volatile("" ::: "memory");
+        if (!(p.vexp && tid < n)) vxw = 127u;
+        vx[tid] = (unsigned)vscale_word(vxw);
+        const unsigned am = max(max(a0, a1), max(a2, a3)) & 0x7fffffffu;
+        const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
+        scale_q16 = make_scale(__uint_as_float(wave_allmax_u32(am)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
+        const float rinv = 1.0f / scale_q16;
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            const bool qvalid = q0 + 32 * x + ql < p.Sq;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                int2 w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(qvalid ? rawq[x][s][i] : make_uint4(0, 0, 0, 0), scale_q16, rinv);
+                st.qf[x][s] = v8i{w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y, w[3].x, w[3].y};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            const int qrow = q0 + 32 * x + ql;
+            const bool qvalid = qrow < p.Sq;
+            const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? qrow : 0)) * D) + hh * 32;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                v4i lo = *reinterpret_cast<const v4i*>(qp + s * 64), hi = *reinterpret_cast<const v4i*>(qp + s * 64 + 16);
+                if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
+                st.qf[x][s] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+    }
+    float c;
+    if (Q16) c = p.sm_log2e * scale_q16 * scalar_load_f32(p.sk + kv_head);
+    else c = p.sm_log2e * scalar_load_f32(p.sq + bh) * scalar_load_f32(p.sk + kv_head);
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        st.m_run[x] = -1.0e30f;
+        st.m_true[x] = -1.0e30f;
+        st.mcv[x] = 0.0f;
+        st.lim[x] = -1.0e30f;
+        w4_to_acc(st.qf[x][0]);
+        w4_to_acc(st.qf[x][1]);
+    }
+    st.c = c;
+    st.vsx = kScaleWordOne;
+    asm volatile(W4_ZERO_ACC_TEXT
+                 : "=" W4_OREG_0(st.o[0][0]), "=" W4_OREG_1(st.o[0][1]), "=" W4_OREG_2(st.o[0][2]), "=" W4_OREG_3(st.o[0][3]), "=" W4_OREG_4(st.o[1][0]),
+                   "=" W4_OREG_5(st.o[1][1]), "=" W4_OREG_6(st.o[1][2]), "=" W4_OREG_7(st.o[1][3]), "=" W4_LSUM_0(st.lsum[0]), "=" W4_LSUM_1(st.lsum[1]),
+                   "=" W4_LSQ_0(st.lsq[0]), "=" W4_LSQ_1(st.lsq[1]));
+
+    w4_sweep<QK_FMT, V_FMT, VS, NEFF, CHECK>(st, p, smem, kg, vg, n, q0, wave, lane, vx);
+
+    // ---- verdict and stores, tile by tile
+    const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
+    unsigned mine[2] = {0u, 0u};
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        const int qrow = q0 + 32 * x + ql;
+        const float s0 = bcast_low16(st.lsum[x][0]), s1 = bcast_low16(st.lsum[x][1]);
+        const float l_tot = (lane & 16) ? s1 : s0;
+        bool keep = true;
+        if (CHECK) {
+            const float t0 = bcast_low16(st.lsq[x][0]), t1 = bcast_low16(st.lsq[x][1]);
+            const float l2_tot = (lane & 16) ? t1 : t0;
+            const float r_inv_pmax = __builtin_amdgcn_exp2f(-(kPShiftByte + (st.m_true[x] - st.m_run[x]) * c));
+            const bool peaked = qrow < p.Sq && row_is_peaked<true, true>(p, l_tot, l2_tot, r_inv_pmax, st.m_true[x] == st.m_run[x], (float)p.Skv);
+            mine[x] = (unsigned)__ballot(peaked);
+            keep = !peaked;
+        }
+        store_o_rows<MB>(p.out, p.out_fmt, st.o[x], sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq && keep);
+    }
+    if (!CHECK) return 0;
+    if (lane == 0) {
+        lds_write_word_raw(vote + 2 * wave, mine[0]);
+        lds_write_word_raw(vote + 2 * wave + 1, mine[1]);
+    }
+    lds_barrier();   // also: every wave is done with the K/V ring
+    int nrows = 0;
+    {
+        v4i va, vb;
+        lds_read_8words_raw(vote, va, vb);
+#pragma unroll
+        for (int w = 0; w < 8; w++) nrows += __builtin_popcount((unsigned)(w < 4 ? va[w & 3] : vb[w & 3]));
+    }
+    return __builtin_amdgcn_readfirstlane(nrows);
+}
+
+template <int QK_FMT, int V_FMT, bool Q16, bool CHECK>
+__global__ __launch_bounds__(kW4Waves * 64, 1) void attn_fwd_kernel_w4(const AttnParams p_arg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const AttnParams& p = p_arg;
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    for (int bid = blockIdx.x; bid < p.total_blocks; bid += (int)gridDim.x) {
+        int tid;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
+        tid |= wave_s << 6;
+        asm volatile("" : "+v"(tid));
+        const int resc = w4_block<QK_FMT, V_FMT, Q16, CHECK>(p, smem, tid, bid);
+        if constexpr (CHECK) {
+            if (resc != 0) {
+                asm volatile("" : "+v"(tid));
+                w4_rescue<QK_FMT, V_FMT, Q16>(p, smem, tid, bid, resc);
+            }
+        }
+        lds_barrier();   // every wave has left the ring and the vote words before the next block fills them
+    }
+}
+
+template <int FMT, bool Q16, bool CHECK>
+static int launch_w4(const AttnParams& pin, hipStream_t st) {
+    AttnParams p = pin;
+    p.total_blocks = p.B * p.Hq * p.nqb;
+    p.sched = nullptr;
+    const int cus = p.xcd_remap ? cu_count() & ~7 : cu_count();
+    const int grid = (cus >= 8 && p.total_blocks > cus) ? cus : p.total_blocks;
+    auto kern = attn_fwd_kernel_w4<FMT, FMT, Q16, CHECK>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kW4Lds) != hipSuccess) return QATTN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kW4Waves * 64), kW4Lds, st, p);
+    return QATTN_OK;
+}
+
+// D = 128, head-wise, non-causal, byte-exponential one-term sweeps (FAST, AUTO) on keys enough that no block starts on the 16-bit V
+bool attn_w4_covers(const AttnParams& p, int D, int causal, int scale_mode) {
+    return D == 128 && scale_mode == QATTN_SCALE_HEAD && !causal && p.lse == nullptr && !p.exact_exp && p.precision != QATTN_PRECISION_ACCURATE &&
+           p.Skv >= p.two_term_keys && p.stamp_buf == nullptr && p.nchunks >= 2;
+}
+
+int launch_attn_w4(const AttnParams& p, int fmt, hipStream_t st) {
+    const bool q16 = p.q16 != nullptr, chk = p.peak_r0 > 0.0f;
+    if (fmt == QATTN_FMT_E4M3) {
+        if (q16) return chk ? launch_w4<QATTN_FMT_E4M3, true, true>(p, st) : launch_w4<QATTN_FMT_E4M3, true, false>(p, st);
+        return chk ? launch_w4<QATTN_FMT_E4M3, false, true>(p, st) : launch_w4<QATTN_FMT_E4M3, false, false>(p, st);
+    }
+    if (q16) return chk ? launch_w4<QATTN_FMT_E5M2, true, true>(p, st) : launch_w4<QATTN_FMT_E5M2, true, false>(p, st);
+    return chk ? launch_w4<QATTN_FMT_E5M2, false, true>(p, st) : launch_w4<QATTN_FMT_E5M2, false, false>(p, st);
+}
+
+}  // namespace qattn

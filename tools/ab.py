@@ -7,7 +7,7 @@ its own operands, and each (library, precision, path) variant is timed with HIP 
                      [--rounds 7] [--calls 20] [--fp8 e4m3] [--scale 1.0] [--settle 0.5]
   paths: fused = qattn_fp8_quant_attention_forward (the bench step), attn = qattn_fp8_attention_forward on pre-quantised
          operands, quant = qattn_quant_qkv_fp8.
-  default libraries: new=quantumattention_amd/libqattn_hip.so r2=tools/bin/libqattn_r2.so (if present)
+  default libraries: new=quantumattention_amd/libqattn_hip.so r2=tools/ab_libs/libqattn_r2.so (if present)
   name=path@VAR=VAL[@VAR2=VAL2]: environment set around that variant's calls (dev library switches that are read per call)
 Prints median / min ms per variant and the ratio to the first library's variant of the same (precision, path).
 """

@@ -2,7 +2,7 @@
 """Development: do two builds of the library produce the same BITS?  (for changes that must not alter results: scheduling, block
 boundaries, prefetches).  Loads both through ctypes (tools/ab.py's Variant), runs the fused step and the separate attention call on
 the same inputs for a few shapes / precisions, prints equal / max-abs difference per case; exit status 1 if any case differs.
-   python tools/cmp_libs.py new=quantumattention_amd/libqattn_hip.so old=tools/bin/libqattn_r3.so"""
+   python tools/cmp_libs.py new=quantumattention_amd/libqattn_hip.so old=tools/ab_libs/libqattn_r3.so"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

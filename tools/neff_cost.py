@@ -5,7 +5,7 @@ import os, re, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from quantumattention_amd import _native
-_native.LIB_PATH = _native.LIB_PATH.replace(".so", "_dev.so")
+_native.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab_libs", "libqattn_dev.so")
 
 def power_w():
     out = subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True).stdout

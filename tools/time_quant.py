@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from quantumattention_amd import _native
-if os.environ.get("USE_DEV", "1") == "1": _native.LIB_PATH = _native.LIB_PATH.replace(".so", "_dev.so")
+if os.environ.get("USE_DEV", "1") == "1": _native.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab_libs", "libqattn_dev.so")
 B, H, S, D = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (4, 32, 4096, 128)))
 torch.manual_seed(0)
 q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
