@@ -103,6 +103,11 @@ __device__ __forceinline__ float w4_byte_offset(float m, float c) {   // the add
 #else
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef W4_ABL
+// timing-only ablations (results wrong): 1 = no stage traffic inside the steps, 2 = no exponentials, 4 = no running maxima, 8 = no barriers in the
+// sweep, 16 = no fragment reads in the steps, 32 = no stage loads, 64 = no stage stores
+#define W4_ABL 0
+#endif
 
 // ---- MFMAs through asm, with the register file each operand lives in spelled out.  Left to the compiler (ROCm 7.2, 512 registers per
 // lane) every accumulator of a kernel goes to one side of the unified file: with the score tiles in AccVGPRs the softmax paid 390
@@ -171,7 +176,7 @@ __device__ __forceinline__ void w4_to_acc(T& x) {
 
 // One pipelined iteration (1 <= t <= n): PV(t-2) and the row sums of P(t-2), QK^T(t), softmax(t-1), for both tiles.  PAR = t & 1.
 //   kbuf  : stage(t), K part (+ lane offset)       vprev : stage(t-1), V part = V(t-2)       vnext : stage(t), V part = V(t-1)
-//   dma(i): moves piece i (0 .. 3) of the stages this iteration is responsible for (w4_sweep: store of stage t + 2, load of stage t + 3)
+//   dma(i): this iteration's stage traffic (w4_sweep): i = 0 .. 3 the loads of stage t + 3's pieces, 4 .. 7 the stores of stage t + 2's
 // A fragment is read two slots (128 matrix-pipe cycles) before the first of the two products it feeds; st.vpre holds row block 0 of
 // V(t-2), read at the end of the previous iteration.
 // FINAL (the peeled last step of a sweep with an odd number of chunks): no QK^T.  It must not issue one "for nobody", as the 8-wave
@@ -181,6 +186,7 @@ __device__ __forceinline__ void w4_to_acc(T& x) {
 // Slot order: PV row blocks 0, 1 | QK^T | PV row blocks 2, 3 | row sums.  The products that END an iteration write pinned AccVGPRs; the
 // score tiles are complete six products before: whatever the compiler puts at a loop exit or a join (it re-homes values there, with
 // plain moves it does not pad) reads scores that have landed, and no late result falls on a register it has given away.
+#define W4_FRAG(PTR) ((W4_ABL & 16) ? st.vpre : lds_read_frag(PTR))
 template <int QK_FMT, int V_FMT, int PAR, bool VS, bool NEFF, bool TRACK, bool FINAL, typename Dma>
 __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* kbuf, const unsigned char* vprev, const unsigned char* vnext,
                                         const unsigned* vx_next, Dma&& dma) {
@@ -192,14 +198,11 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     const float mcA = st.mcv[0], mcB = st.mcv[1];
     float aA, bA, cA, aB, bB, cB;
     v8i ka, kb, kc, kd;
-#ifndef W4_ABL
-#define W4_ABL 0   // timing-only ablations (results wrong): 1 = no stage requests inside the steps, 2 = no exponentials, 4 = no running maxima
-#endif
 #define W4_GROUP(X, G, MC) do { if (!(W4_ABL & 2)) w4_byte_group(sc[X][(G) >> 2], (G)&3, cx, MC, pc[X], G); } while (0)
     // slot 0
     w4_pv<0, V_FMT, VS>(st.o[0][0], st.vpre, pp[0], st.vsx);
     W4_FENCE();
-    const v8i v1 = lds_read_frag(vprev + (1 << 11));
+    const v8i v1 = W4_FRAG(vprev + (1 << 11));
     W4_GROUP(0, 0, mcA);
     w4_max_pair<0>(sc[0][0], sc[0][1], aA, bA, cA);
     W4_FENCE();
@@ -212,7 +215,7 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     // slot 2
     w4_pv<1, V_FMT, VS>(st.o[0][1], v1, pp[0], st.vsx);
     W4_FENCE();
-    if constexpr (!FINAL) ka = lds_read_frag(kbuf + (0 << 11));   // K(tile 0, k-step 0)
+    if constexpr (!FINAL) ka = W4_FRAG(kbuf + (0 << 11));   // K(tile 0, k-step 0)
     W4_GROUP(0, 2, mcA);
     w4_max_pair<2>(sc[0][0], sc[0][1], aA, bA, cA);
     W4_FENCE();
@@ -225,7 +228,7 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     // slot 4: S(t) = K.Q^T, both tiles per K fragment
     if constexpr (!FINAL) w4_qk0<QK_FMT>(sn[0][0], ka, st.qf[0][0]);
     W4_FENCE();
-    if constexpr (!FINAL) kb = lds_read_frag(kbuf + (2 << 11));   // K(tile 1, k-step 0)
+    if constexpr (!FINAL) kb = W4_FRAG(kbuf + (2 << 11));   // K(tile 1, k-step 0)
     W4_GROUP(0, 4, mcA);
     w4_max_pair<4>(sc[0][0], sc[0][1], aA, bA, cA);
     W4_FENCE();
@@ -238,7 +241,7 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     // slot 6
     if constexpr (!FINAL) w4_qk0<QK_FMT>(sn[0][1], kb, st.qf[0][0]);
     W4_FENCE();
-    if constexpr (!FINAL) kc = lds_read_frag(kbuf + (1 << 11));   // K(tile 0, k-step 1)
+    if constexpr (!FINAL) kc = W4_FRAG(kbuf + (1 << 11));   // K(tile 0, k-step 1)
     W4_GROUP(0, 6, mcA);
     w4_max_pair<6>(sc[0][0], sc[0][1], aA, bA, cA);
     W4_FENCE();
@@ -251,7 +254,7 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     // slot 8
     if constexpr (!FINAL) w4_qk1<QK_FMT>(sn[0][0], kc, st.qf[0][1]);
     W4_FENCE();
-    if constexpr (!FINAL) kd = lds_read_frag(kbuf + (3 << 11));   // K(tile 1, k-step 1)
+    if constexpr (!FINAL) kd = W4_FRAG(kbuf + (3 << 11));   // K(tile 1, k-step 1)
     W4_GROUP(1, 0, mcB);
     w4_max_pair<0>(sc[1][0], sc[1][1], aB, bB, cB);
     const float mxA = w4_max_finish<TRACK>(aA, bA, cA, st.m_true[0]);
@@ -266,7 +269,7 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     // slot 10
     if constexpr (!FINAL) w4_qk1<QK_FMT>(sn[0][1], kd, st.qf[0][1]);
     W4_FENCE();
-    const v8i v2 = lds_read_frag(vprev + (2 << 11));
+    const v8i v2 = W4_FRAG(vprev + (2 << 11));
     W4_GROUP(1, 2, mcB);
     w4_max_pair<2>(sc[1][0], sc[1][1], aB, bB, cB);
     W4_FENCE();
@@ -280,7 +283,7 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     // slot 12
     w4_pv<2, V_FMT, VS>(st.o[0][2], v2, pp[0], st.vsx);
     W4_FENCE();
-    const v8i v3 = lds_read_frag(vprev + (3 << 11));
+    const v8i v3 = W4_FRAG(vprev + (3 << 11));
     W4_GROUP(1, 4, mcB);
     w4_max_pair<4>(sc[1][0], sc[1][1], aB, bB, cB);
     W4_FENCE();
@@ -294,7 +297,7 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     // slot 14
     w4_pv<3, V_FMT, VS>(st.o[0][3], v3, pp[0], st.vsx);
     W4_FENCE();
-    const v8i vnx = lds_read_frag(vnext + (0 << 11));   // row block 0 of the NEXT iteration's V
+    const v8i vnx = W4_FRAG(vnext + (0 << 11));   // row block 0 of the NEXT iteration's V
     int vsn = st.vsx;
     if (VS) vsn = (int)*vx_next;                        // ... and its scale byte
     W4_GROUP(1, 6, mcB);
@@ -311,12 +314,16 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
     w4_rowsum<0, false>(st.lsum[0], st.ones, pp[0]);
     if (NEFF) w4_rowsum<0, true>(st.lsq[0], st.ones, pp[0]);
     W4_FENCE();
+    dma(4);
+    dma(5);
     const float mxB = w4_max_finish<TRACK>(aB, bB, cB, st.m_true[1]);
     W4_FENCE();
     // slot 17: ... tile B
     w4_rowsum<1, false>(st.lsum[1], st.ones, pp[1]);
     if (NEFF) w4_rowsum<1, true>(st.lsq[1], st.ones, pp[1]);
     W4_FENCE();
+    dma(6);
+    dma(7);
     st.vpre = vnx;
     st.vsx = vsn;
     const bool growA = mxA > st.lim[0], growB = mxB > st.lim[1];
@@ -363,27 +370,34 @@ __device__ __forceinline__ void w4_step(W4State<NEFF>& st, const unsigned char* 
 // products) V(t-1) from stage t, V(t-2) from stage t-1.  The first three stages of a block come by LDS-DMA (w4_block, with the block's
 // other loads).  Inside the sweep a stage travels THROUGH REGISTERS: a lone wave pays every LDS-DMA request with ~60 issue cycles that
 // nothing covers (the C2 launch ran 14 % faster without the four requests per iteration, profiles/r05/ab_w4_ablations.log), a
-// global_load_dwordx4 + ds_write_b128 pair costs a third of that.  Iteration t: piece i (slots 9, 11, 13, 15) of stage t + 2, loaded
-// during iteration t - 1 into four pinned AccVGPRs, is written to LDS (s_waitcnt vmcnt(3): three younger loads may be in flight), and
-// the same registers take the load of piece i of stage t + 3.  The waves meet at the top of every EVEN iteration (s_waitcnt
-// lgkmcnt(0) + s_barrier): the stores of iterations t - 2 and t - 1 -- stages t and t + 1, which the next two iterations read -- are
-// complete.  The slot stage s + kW4Stages overwrites is written in iteration s + 3, behind the barrier of iteration s + 2 or s + 3,
-// by which every wave has left iteration s + 1, the last reader of stage s.
+// global_load_dwordx4 costs ~12 and a ds_write_b128 ~26 (profiles/r05/w4_clock_staging.log).  Two sets of four pinned AccVGPRs:
+// iteration t loads the four pieces of stage t + 3 into set (t - 1) & 1 (slots 9, 11, 13, 15) and, at its end (slots 16, 17: the short
+// row-sum products), stores the pieces of stage t + 2 -- loaded during iteration t - 1, a good iteration earlier: under load an L2 hit
+// takes most of one -- from set t & 1 (s_waitcnt vmcnt(7 - i): the set's younger pieces and the other set may be in flight).  The
+// waves meet at the top of every EVEN iteration (s_waitcnt lgkmcnt(0) + s_barrier): the stores of iterations t - 2 and t - 1 -- stages
+// t and t + 1, which the next two iterations read -- are complete.  The slot stage s + kW4Stages overwrites is written at the end of
+// iteration s + 3, behind the barrier of iteration s + 2 or s + 3, by which every wave has left iteration s + 1, the last reader of
+// stage s.
 #define W4_STG_0 "{a[200:203]}"
 #define W4_STG_1 "{a[204:207]}"
 #define W4_STG_2 "{a[208:211]}"
 #define W4_STG_3 "{a[212:215]}"
-struct W4Staging { v4i r[4]; };
-template <int I>
+#define W4_STG_4 "{a[216:219]}"
+#define W4_STG_5 "{a[220:223]}"
+#define W4_STG_6 "{a[224:227]}"
+#define W4_STG_7 "{a[228:231]}"
+struct W4Staging { v4i r[8]; };   // two sets of four pieces (set = index >> 2)
+template <int J>
 __device__ __forceinline__ void w4_stage_load(W4Staging& g, unsigned off, const unsigned char* base) {
-#define W4_LD(i) if constexpr (I == i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=" W4_STG_##i(g.r[i]) : "v"(off), "s"(base) : "memory");
-    W4_LD(0) W4_LD(1) W4_LD(2) W4_LD(3)
+#define W4_LD(j) if constexpr (J == j) asm volatile("global_load_dwordx4 %0, %1, %2" : "=" W4_STG_##j(g.r[j]) : "v"(off), "s"(base) : "memory");
+    W4_LD(0) W4_LD(1) W4_LD(2) W4_LD(3) W4_LD(4) W4_LD(5) W4_LD(6) W4_LD(7)
 #undef W4_LD
 }
-template <int I, int OFF>
+// the store of piece J & 3: the loads younger than its own are the rest of its set and the whole other set (3 - (J & 3) + 4)
+template <int J, int OFF>
 __device__ __forceinline__ void w4_stage_store(const W4Staging& g, unsigned lds_addr) {
-#define W4_ST(i) if constexpr (I == i) asm volatile("s_waitcnt vmcnt(3)\n\tds_write_b128 %0, %1 offset:%2" ::"v"(lds_addr), W4_STG_##i(g.r[i]), "n"(OFF) : "memory");
-    W4_ST(0) W4_ST(1) W4_ST(2) W4_ST(3)
+#define W4_ST(j) if constexpr (J == j) asm volatile("s_waitcnt vmcnt(%3)\n\tds_write_b128 %0, %1 offset:%2" ::"v"(lds_addr), W4_STG_##j(g.r[j]), "n"(OFF), "n"(7 - (j & 3)) : "memory");
+    W4_ST(0) W4_ST(1) W4_ST(2) W4_ST(3) W4_ST(4) W4_ST(5) W4_ST(6) W4_ST(7)
 #undef W4_ST
 }
 template <int QK_FMT, int V_FMT, bool VS, bool NEFF, bool TRACK>
@@ -400,29 +414,36 @@ __device__ __forceinline__ void w4_sweep(W4State<NEFF>& st, const AttnParams& p,
     const unsigned lane_piece = ((unsigned)wave << 10) + ((unsigned)lane << 4);
     const unsigned lds_lane = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + lane_piece;
     W4Staging stg;
-    auto stage_load = [&](auto i_tag) __attribute__((always_inline)) {
-        constexpr int I = decltype(i_tag)::value;
+    auto stage_load = [&](auto j_tag) __attribute__((always_inline)) {   // piece J & 3 into set J >> 2
+        constexpr int J = decltype(j_tag)::value, I = J & 3;
         const unsigned off = (I < 2 ? koff : voff) + lane_piece + ((I & 1) ? 4096u : 0u);
-        w4_stage_load<I>(stg, off, I < 2 ? kg : vg);
+        w4_stage_load<J>(stg, off, I < 2 ? kg : vg);
         if constexpr (I == 3) {
             voff = koff;
             koff = min(koff + (unsigned)CH, koff_max);
         }
     };
-    auto stage_store = [&](auto i_tag) __attribute__((always_inline)) {
-        constexpr int I = decltype(i_tag)::value;
-        w4_stage_store<I, (I < 2 ? 0 : CH) + ((I & 1) ? 4096 : 0)>(stg, lds_lane + lds_w);
+    auto stage_store = [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value, I = J & 3;
+        w4_stage_store<J, (I < 2 ? 0 : CH) + ((I & 1) ? 4096 : 0)>(stg, lds_lane + lds_w);
         if constexpr (I == 3) lds_w = lds_w + STAGE == kW4Ring ? 0u : lds_w + STAGE;
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    auto stage_piece = [&](int i) __attribute__((always_inline)) {   // (i is a literal at every call site)
-        if (i == 0) { stage_store(I0{}); stage_load(I0{}); }
-        if (i == 1) { stage_store(I1{}); stage_load(I1{}); }
-        if (i == 2) { stage_store(I2{}); stage_load(I2{}); }
-        if (i == 3) { stage_store(I3{}); stage_load(I3{}); }
+    // hook of the steps: calls 0 .. 3 = the loads (slots 9, 11, 13, 15), 4 .. 7 = the stores (slots 16, 17); PAR = t & 1
+    // (W4_ABL 32: no loads, 64: no stores -- timing only)
+    auto stage_piece = [&](auto par_tag, int i) __attribute__((always_inline)) {   // (i is a literal at every call site)
+        constexpr int PAR = decltype(par_tag)::value, LS = 4 * (PAR ^ 1), SS = 4 * PAR;
+        if (!(W4_ABL & 32)) {
+            if (i == 0) stage_load(std::integral_constant<int, LS + 0>{});
+            if (i == 1) stage_load(std::integral_constant<int, LS + 1>{});
+            if (i == 2) stage_load(std::integral_constant<int, LS + 2>{});
+            if (i == 3) stage_load(std::integral_constant<int, LS + 3>{});
+        }
+        if (!(W4_ABL & 64)) {
+            if (i == 4) stage_store(std::integral_constant<int, SS + 0>{});
+            if (i == 5) stage_store(std::integral_constant<int, SS + 1>{});
+            if (i == 6) stage_store(std::integral_constant<int, SS + 2>{});
+            if (i == 7) stage_store(std::integral_constant<int, SS + 3>{});
+        }
     };
     unsigned slot_cur = 0, slot_prev = 0;
     auto sync_top = [&](int t) __attribute__((always_inline)) {   // top of iteration t
@@ -432,7 +453,7 @@ __device__ __forceinline__ void w4_sweep(W4State<NEFF>& st, const AttnParams& p,
         if ((t & 1) == 0) {
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stores of the last two iterations
-            __builtin_amdgcn_s_barrier();
+            if (!(W4_ABL & 8)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
             asm volatile("s_nop 0" ::: "memory");   // keeps the iterations of a pair separate scheduling regions
@@ -473,7 +494,9 @@ __device__ __forceinline__ void w4_sweep(W4State<NEFF>& st, const AttnParams& p,
             w4_qk1<QK_FMT>(st.s[0][1][1], kd, st.qf[1][1]);
         }
         st.vpre = lds_read_frag(kbuf + CH + (0 << 11));   // stage(0)'s V part (= V(0), multiplied by P = 0 at t = 1)
-        stage_load(I0{}); stage_load(I1{}); stage_load(I2{}); stage_load(I3{});   // stage 3 (stored by iteration 1)
+        // stage 3 into set 1 (stored at the end of iteration 1)
+        stage_load(std::integral_constant<int, 4>{}); stage_load(std::integral_constant<int, 5>{});
+        stage_load(std::integral_constant<int, 6>{}); stage_load(std::integral_constant<int, 7>{});
         advance();
         w4_mfma_drain();   // the score tiles are read right away
 #pragma unroll
@@ -502,7 +525,7 @@ __device__ __forceinline__ void w4_sweep(W4State<NEFF>& st, const AttnParams& p,
         advance();
         // (every iteration moves a stage: beyond stage n the clamped source re-reads the head's last chunk into a slot nobody reads again;
         // a branch inside the step would split it into basic blocks)
-        w4_step<QK_FMT, V_FMT, PAR, VS, NEFF, TRACK, FINAL>(st, kbuf, vprev, kbuf + CH, vx_next, [&](int i) __attribute__((always_inline)) { if (!(W4_ABL & 1)) stage_piece(i); });
+        w4_step<QK_FMT, V_FMT, PAR, VS, NEFF, TRACK, FINAL>(st, kbuf, vprev, kbuf + CH, vx_next, [&](int i) __attribute__((always_inline)) { if (!(W4_ABL & 1)) stage_piece(par_tag, i); });
         if constexpr (VS) vx_next = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(vx_next) + vx_step);
     };
     // keys at or beyond Skv -> -inf, without compares: the test code sits inside the sweep's only loop, and 64 compare masks in scalar
@@ -563,7 +586,9 @@ __device__ __forceinline__ void w4_sweep(W4State<NEFF>& st, const AttnParams& p,
         };
         tail(P1{});
         // the last iteration's loads land in the pinned staging registers: wait for them while those still belong to this loop
-        asm volatile("s_waitcnt vmcnt(0)" ::W4_STG_0(stg.r[0]), W4_STG_1(stg.r[1]), W4_STG_2(stg.r[2]), W4_STG_3(stg.r[3]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::W4_STG_0(stg.r[0]), W4_STG_1(stg.r[1]), W4_STG_2(stg.r[2]), W4_STG_3(stg.r[3]), W4_STG_4(stg.r[4]), W4_STG_5(stg.r[5]),
+                     W4_STG_6(stg.r[6]), W4_STG_7(stg.r[7])
+                     : "memory");
         w4_mfma_drain();   // the caller reads the accumulators
     }
 }
@@ -658,7 +683,10 @@ __device__ __forceinline__ void w4_rescue(const AttnParams& p, unsigned char* sm
 }
 
 // One 256-row query block.  Returns the number of its rows left to w4_rescue (CHECK only; their vote words are in LDS).
-template <int QK_FMT, int V_FMT, bool Q16, bool CHECK>
+// STAMP: the measurement instantiation (qattn_fp8_quant_attention_forward_stamped): every wave brackets its KV sweep with the shader-cycle
+// counter and the 100 MHz real-time counter (MI355X_MICROARCH.md, DVFS give-back item 6); the stamps go to a buffer of their own and
+// nothing is computed from them.  The product instantiations execute no stamp.
+template <int QK_FMT, int V_FMT, bool Q16, bool CHECK, bool STAMP = false>
 __device__ __forceinline__ int w4_block(const AttnParams& p, unsigned char* smem, int tid, int bid) {
     constexpr int D = kW4D, CH = kW4CH, STAGE = kW4Stage, KS = 2, MB = 4;
     constexpr bool VS = Q16, NEFF = CHECK;
@@ -806,7 +834,21 @@ __device__ __forceinline__ int w4_block(const AttnParams& p, unsigned char* smem
                    "=" W4_OREG_5(st.o[1][1]), "=" W4_OREG_6(st.o[1][2]), "=" W4_OREG_7(st.o[1][3]), "=" W4_LSUM_0(st.lsum[0]), "=" W4_LSUM_1(st.lsum[1]),
                    "=" W4_LSQ_0(st.lsq[0]), "=" W4_LSQ_1(st.lsq[1]));
 
+    unsigned long long stamp_t0 = 0, stamp_r0 = 0;
+    if constexpr (STAMP) {
+        stamp_t0 = __builtin_amdgcn_s_memtime();
+        stamp_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    }
     w4_sweep<QK_FMT, V_FMT, VS, NEFF, CHECK>(st, p, smem, kg, vg, n, q0, wave, lane, vx);
+    if constexpr (STAMP) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && p.stamp_buf) {
+            const long wid = (bh * p.nqb + qb) * kWaves + wave;   // (the buffer is sized for the 8-wave kernel: entries 4 .. 7 of a block stay empty)
+            p.stamp_buf[2 * wid] = t1 - stamp_t0;
+            p.stamp_buf[2 * wid + 1] = r1 - stamp_r0;
+        }
+    }
 
     // ---- verdict and stores, tile by tile
     const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
@@ -843,7 +885,7 @@ __device__ __forceinline__ int w4_block(const AttnParams& p, unsigned char* smem
     return __builtin_amdgcn_readfirstlane(nrows);
 }
 
-template <int QK_FMT, int V_FMT, bool Q16, bool CHECK>
+template <int QK_FMT, int V_FMT, bool Q16, bool CHECK, bool STAMP = false>
 __global__ __launch_bounds__(kW4Waves * 64, 1) void attn_fwd_kernel_w4(const AttnParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AttnParams& p = p_arg;
@@ -853,7 +895,7 @@ __global__ __launch_bounds__(kW4Waves * 64, 1) void attn_fwd_kernel_w4(const Att
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
         tid |= wave_s << 6;
         asm volatile("" : "+v"(tid));
-        const int resc = w4_block<QK_FMT, V_FMT, Q16, CHECK>(p, smem, tid, bid);
+        const int resc = w4_block<QK_FMT, V_FMT, Q16, CHECK, STAMP>(p, smem, tid, bid);
         if constexpr (CHECK) {
             if (resc != 0) {
                 asm volatile("" : "+v"(tid));
@@ -871,6 +913,15 @@ static int launch_w4(const AttnParams& pin, hipStream_t st) {
     p.sched = nullptr;
     const int cus = p.xcd_remap ? cu_count() & ~7 : cu_count();
     const int grid = (cus >= 8 && p.total_blocks > cus) ? cus : p.total_blocks;
+    if constexpr (FMT == QATTN_FMT_E4M3 && Q16) {
+        if (p.stamp_buf) {   // measurement entry: the same kernel with the two clock stamps per wave
+            auto kern1 = attn_fwd_kernel_w4<FMT, FMT, Q16, CHECK, true>;
+            if (hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, kW4Lds) != hipSuccess) return QATTN_ERR_LAUNCH;
+            hipLaunchKernelGGL(kern1, dim3(grid), dim3(kW4Waves * 64), kW4Lds, st, p);
+            return QATTN_OK;
+        }
+    }
+    if (p.stamp_buf) return QATTN_ERR_UNSUPPORTED_FMT;   // (only the fused e4m3 step has a stamped instantiation)
     auto kern = attn_fwd_kernel_w4<FMT, FMT, Q16, CHECK>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kW4Lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kW4Waves * 64), kW4Lds, st, p);
@@ -880,7 +931,7 @@ static int launch_w4(const AttnParams& pin, hipStream_t st) {
 // D = 128, head-wise, non-causal, byte-exponential one-term sweeps (FAST, AUTO) on keys enough that no block starts on the 16-bit V
 bool attn_w4_covers(const AttnParams& p, int D, int causal, int scale_mode) {
     return D == 128 && scale_mode == QATTN_SCALE_HEAD && !causal && p.lse == nullptr && !p.exact_exp && p.precision != QATTN_PRECISION_ACCURATE &&
-           p.Skv >= p.two_term_keys && p.stamp_buf == nullptr && p.nchunks >= 2;
+           p.Skv >= p.two_term_keys && p.nchunks >= 2;
 }
 
 int launch_attn_w4(const AttnParams& p, int fmt, hipStream_t st) {
