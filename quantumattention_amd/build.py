@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, "libqattn_hip.so")
 # the dev library (ablations, cycle stamps, QATTN_* environment switches) is a tool: it lives beside the A/B baselines, not
 # beside the product library
 DEV_LIB = os.path.join(os.path.dirname(HERE), "tools", "ab_libs", "libqattn_dev.so")
-SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip", "qattn_attn_pv16.hip", "qattn_attn_w4.hip"]
+SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip", "qattn_attn_pv16.hip"]
 # (source, extra flags, object name): the two big kernel files are compiled once per operand format / head dimension so that
 # the build runs in parallel (the longest single translation unit sets the wall time)
 # (a unit with a define is compiled through a two-line wrapper file named after the unit, so that -save-temps leaves one .s
@@ -37,7 +37,6 @@ UNITS = [
     ("qattn_api.hip", [], "qattn_api"),
     ("qattn_probe.hip", [], "qattn_probe"),
     ("qattn_attn_pv16.hip", [], "qattn_attn_pv16"),
-    ("qattn_attn_w4.hip", [], "qattn_attn_w4"),
 ]
 # `--dev` builds tools/ab_libs/libqattn_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
 # QATTN_* environment switches.  The product library contains none of them.

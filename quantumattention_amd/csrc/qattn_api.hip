@@ -59,10 +59,6 @@ DeviceState* device_state(bool may_create) {
     return &s;
 }
 
-#ifndef QATTN_USE_W4
-#define QATTN_USE_W4 1   // (a build knob for tools/ab.py variants: 0 = the 8-wave kernel everywhere)
-#endif
-
 bool stream_is_capturing(hipStream_t st) {
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(st, &status) == hipSuccess && status != hipStreamCaptureStatusNone;
@@ -202,7 +198,6 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     }
     if (rc != QATTN_OK) { /* fall through to the error return below */ }
     else if (v_is_16) rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
-    else if (use_v2 && QATTN_USE_W4 && attn_w4_covers(p, a.D, a.is_causal, a.scale_mode)) rc = launch_attn_w4(p, a.qk_fmt, st);
     else if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     else rc = launch_attn_v4_full(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     if (side) {

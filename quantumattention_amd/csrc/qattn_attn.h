@@ -514,7 +514,7 @@ template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QL
 __device__ __forceinline__ void rescue_rows_at(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                                int row, bool store, int row_lo, int row_hi, int wave, int lane, long bh, long kv_head, float c,
                                                const float* skt, QFrag&& qfrag, const unsigned* vx = nullptr) {   // vx: the V chunks' scale bytes (LDS), nullptr: unscaled V
-    static_assert(NW == 8 || NW == 4, "log2(NW) merge rounds");
+    static_assert(NW == 8, "three merge rounds");
     constexpr int CH = 64 * D, KS = D / 64, MB = D / 32;
     constexpr int SLOT = rescue_slot_bytes<D>();
     constexpr bool QPRE = D <= 128 && !QLDS;   // Q^T fragments held in registers (D = 256: re-fetched per chunk, registers go to
@@ -694,9 +694,6 @@ int launch_attn_v2_e5m2(const AttnParams& p, int causal, int scale_mode, hipStre
 int launch_attn_v4_d64(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v4_d128(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v4_d256(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
-// 4 waves x 64 query rows, one wave per SIMD (qattn_attn_w4.hip): the cases it covers, and its launch
-bool attn_w4_covers(const AttnParams& p, int D, int causal, int scale_mode);
-int launch_attn_w4(const AttnParams& p, int fmt, hipStream_t st);
 
 // true when the hand-scheduled kernel (qattn_attn_v2.hip) covers the case: D = 128 with head-wise scales.  Token-wise scales
 // need 32 more registers per chunk for the per-key factors, which does not fit 256 registers at two waves per SIMD next

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Development: in-kernel clock and sweep cycles per wave of the fused C2 step (stamped instantiation), for one or more builds.
-   python tools/w4_clock.py name=path ... [--prec fast]"""
+"""Development: in-kernel clock and KV-sweep cycles per wave of the fused C2 step (stamped instantiation of the attention kernel), for one or
+more builds of the library.
+   python tools/kernel_clock.py name=path ... [--prec fast]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantumattention_amd import _native
