@@ -1,5 +1,6 @@
 """ctypes binding of libqattn_hip.so (include/qattn.h).  No CPU fallback: a missing library is a hard error."""
 import ctypes
+import math
 import os
 from typing import Optional, Tuple
 
@@ -422,10 +423,16 @@ def measure_mfma_peak(device=None, *, seconds: float = 0.3, iters: int = 20000, 
                               "qattn_mfma_probe")
         call()
         torch.cuda.synchronize(dev)
-        import time as _time
-
-        t_end, laps = _time.perf_counter() + seconds, []
-        while _time.perf_counter() < t_end or len(laps) < 3:
+        # the lap count bounds GPU time, not host time: launches are asynchronous (6 ms each), and a loop bounded by the host clock
+        # queued 5500 of them -- 33 s of dense matrix work in front of every later measurement
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        n_laps = max(3, min(200, int(math.ceil(seconds * 1e3 / max(e0.elapsed_time(e1), 1e-3)))))
+        laps = []
+        for _ in range(n_laps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             call()

@@ -11,6 +11,27 @@ import json
 import os
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _commit():
+    import subprocess
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        return "unknown"
+
+
+def _csrc_sha16():   # (bench.py csrc_sha16: the same bytes in the same order)
+    import hashlib
+    h, d = hashlib.sha256(), os.path.join(ROOT, "quantumattention_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 src, dst = sys.argv[1], sys.argv[2]
 shape = tuple(int(x) for x in sys.argv[3:7]) if len(sys.argv) >= 7 else (4, 32, 4096, 128)
 causal = len(sys.argv) >= 8 and sys.argv[7] not in ("0", "false")
@@ -61,6 +82,9 @@ if attn:
         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; %s/pmc_summary.json" % dst,
         "algorithmic_bytes": B * H * S * D * ((2 + 1 + 1 + 2) if fused else (3 + 2)),  # Q (bf16 or fp8) + K + V fp8 + O bf16
         "kernel": key,
+        # which tree the counters belong to: bench.py reports whether the kernel sources have changed since (it cannot collect counters itself)
+        "commit": _commit(),
+        "csrc_sha16": _csrc_sha16(),
     }
     if causal:   # K/V re-streaming if no query block shared them = (#256-row blocks per head) x 1/2 x (K + V per head)
         out["kv_restream_bytes_without_l2_reuse"] = B * H * (S // 256) * (S * D * 2) // 2
