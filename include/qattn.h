@@ -22,8 +22,9 @@
  *     queued on `stream` before it and ends before everything queued after it; inside, a causal attention call on the templated
  *     kernel (D = 64 / 256, token-wise scales, fp16 inputs) runs the launch of its early rows on ONE internal non-blocking stream per
  *     host thread and device, forked from and joined to `stream` with events (two parallel branches under capture).  That stream
- *     and its two events are created on the thread's first such call outside a capture (a capturing call before that runs its
- *     launches one after the other) and live until the process ends;
+ *     and its two events are the one exception to "no allocation": they are created on the thread's first such call outside a
+ *     capture (a capturing call before that runs its launches one after the other; if the creation fails, every later call of the
+ *     thread stays on `stream`) and are destroyed when the host thread exits;
  *   - return 0 on success or a negative QATTN_ERR_* code; nothing is thrown; qattn_strerror() names the code.
  *
  * Fragment layouts (private to this library; produced by qattn_quant_fp8 / qattn_pack_fp8, consumed by the
@@ -152,7 +153,7 @@ int qattn_pack_fp8(const void* x8_rowmajor, void* x8_packed, int B, int H, int S
  *             or (v_fmt = QATTN_FMT_BF16 / QATTN_FMT_FP16 = out_fmt) the ORIGINAL 16-bit value tensor, dense ROW-MAJOR, no scale_v:
  *             every row then runs the reference kernel's own P.V numerics -- FP8 QK^T, 16-bit P, 16-bit V (tk/attention.py:72,286,318) --
  *             on v_mfma_f32_32x32x16_{bf16,f16} (csrc/qattn_pv16.h; about 1.5x the time; `precision` plays no part: P carries 8 / 11
- *             mantissa bits).  Other head dims: QATTN_ERR_UNSUPPORTED_FMT.
+ *             mantissa bits).  Every supported head dim (64 / 128 / 256), head- and token-wise scales, e4m3 / e5m2 q and k.
  *   out       [B,Hq,Sq,D]   bf16 or fp16 (out_fmt), row-major, written in full
  *   lse       NULL, or fp32 log-sum-exp of the scaled scores per query row in `lse_layout` (B*Hq rows of
  *             qattn_lse_row_stride(Sq, lse_layout) floats) -- the per-row vector the reference defines but disables

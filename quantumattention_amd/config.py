@@ -32,9 +32,11 @@ class attention:
 
     # the P.V product of `fp8_attention_forward` on pre-quantised query / key (the reference's op contract: value arrives in 16 bit):
     #   "fp8"    (default) value is quantised to fp8 per head and both GEMMs run on FP8 MFMA (north_star)
-    #   "16bit"  the reference kernel's own numerics: 16-bit P on the un-quantised value, bf16 / fp16 MFMA (head_dim 128; about
-    #            1.5x the time).  Independently of this switch the fused step `fp8_attn_func(16-bit q, k, v)` attends the original
+    #   "16bit"  the reference kernel's own numerics: 16-bit P on the un-quantised value, bf16 / fp16 MFMA (head_dim 64 / 128 / 256;
+    #            about 1.5x the time).  Independently of this switch the fused step `fp8_attn_func(16-bit q, k, v)` attends the original
     #            16-bit V for the query blocks that see fewer than 1024 keys (early causal rows, short sequences).
+    #   Read PER CALL inside the op body (ops.fp8_attention_forward), unlike precision / fp8_format / quant_numerics, which the fused op
+    #   takes as arguments and a compiled graph therefore bakes in at trace time: a compiled region follows a later change of this flag.
     pv_precision = os.getenv("QUANTUM_ATTN_PV_PRECISION", "fp8")
 
     # torch.compile: trace the per-head abs-max (and sums of squares) of query / key / value into the caller's graph as aten reductions, so

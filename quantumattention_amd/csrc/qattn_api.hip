@@ -354,9 +354,20 @@ bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
 namespace qattn {
 // ---- side stream (declared in qattn_attn.h)
 struct SideStream {
-    bool ready = false;
+    bool ready = false, failed = false;
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    void release() {
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (s) (void)hipStreamDestroy(s);
+        fork = join = nullptr;
+        s = nullptr;
+        ready = false;
+    }
+    // a host thread that exits gives its stream and events back (thread-pool servers).  (At process exit the runtime may be
+    // gone already: the destroy calls then fail harmlessly.)
+    ~SideStream() { release(); }
 };
 thread_local SideStream t_side[kMaxDevices];
 
@@ -368,10 +379,17 @@ hipStream_t side_stream_fork(hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
     SideStream& x = t_side[dev];
+    if (x.failed) return nullptr;   // creation failed once on this thread: single-stream from then on, no retry (and no leak per call)
     if (!x.ready) {
         if (stream_is_capturing(st)) return nullptr;   // (no object creation inside a capture)
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+            x.release();   // whatever was created
+            x.failed = true;
+            (void)hipGetLastError();
+            return nullptr;
+        }
         x.ready = true;
     }
     if (hipEventRecord(x.fork, st) != hipSuccess || hipStreamWaitEvent(x.s, x.fork, 0) != hipSuccess) return nullptr;

@@ -1266,9 +1266,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
         if (wlog && threadIdx.x == 0) wlog[2] = __builtin_amdgcn_s_memrealtime();
 #endif
         if constexpr (CHECK && !TOKEN && NW == 8) {
-            // a few peaked 32-row groups: on the spot, while the head's K / V are in this XCD's L2 (every wave is past the vote
-            // barrier, hence done with the K/V ring).  The next block is drawn afterwards: a block reserved before the rescue would
-            // wait for it while other workgroups idle (+16 us at the end of a C3 launch).
+            // a few peaked rows: on the spot, while the head's K / V are in this XCD's L2 (every wave is past the vote barrier, hence
+            // done with the K/V ring).  The block's successor HAS been drawn by then (draw_issue / draw_finish inside attend_block, before the
+            // vote barrier: requested behind the row stores the atomic cost every block 1.2 - 2 us); it waits for the rescue -- the
+            // trade round 4 measured (C3 -2.8 % against drawing after the stores; a block held through a rescue adds to the tail).
             if (resc != 0) {
                 QATTN_PARAMS();
                 asm volatile("" : "+v"(tid));

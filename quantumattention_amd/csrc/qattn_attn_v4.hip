@@ -466,8 +466,10 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
     const int rows_all = ceil_div(p.Sq, 256) * 256;
     int rows_two;
     if (p.precision == QATTN_PRECISION_ACCURATE) rows_two = rows_all;
-    else if (causal) rows_two = min(rows_all, ceil_div(min(p.two_term_keys, p.Skv), 256) * 256);
-    else rows_two = p.Skv < p.two_term_keys ? rows_all : 0;
+    // (the early set is pv16_early_blocks' -- the D = 128 kernel, the fp16 side launch, include/qattn.h and the tests' oracle all use it: with
+    // fewer than two_term_keys keys EVERY block is early, causal or not, whatever Sq; ADVICE r4: clamped by the key count, causal calls
+    // with Sq > Skv < 1024 left their later rows on one-term fp8 P)
+    else rows_two = min(rows_all, pv16_early_blocks(p.Sq, p.Skv, causal, p.two_term_keys) * 256);
     const bool byte_exp = !p.exact_exp && p.lse == nullptr;
     const bool rescue = p.peak_r0 > 0.0f && rows_two < p.Sq;
     if (rescue) {

@@ -347,7 +347,13 @@ def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_
             # them into the producer's kernel -- and handed to the op, whose abs-max launch then has nothing left to read
             # (qattn_fp8_quant_attention_forward_ex).  abs().amax() of a 16-bit tensor is exact, so the scales and the output are
             # those of the eager call bit for bit (sums of squares: include/qattn.h on the dead-band edge).
-            amax_q, amax_k, amax_v = (_head_abs_max(t) for t in (query, key, value))
+            amax_q, amax_k = _head_abs_max(query), _head_abs_max(key)
+            # V's abs-max only where V gets one scale per head: on the block-scaled paths (the headline one among them) the op never
+            # reads it, and an op input cannot be eliminated as dead code -- the graph would carry a full extra read of V.
+            # head_dim, dtype and the key length are static at trace time (mark_static above; a symbolic length counts as long).
+            skv = key.shape[-2]
+            if not isinstance(skv, int) or checks.fused_step_scales_v_per_head(query.shape[-1], query.dtype, scaling_method, skv):
+                amax_v = _head_abs_max(value)
             if _cfg("precision") == "auto":
                 ssq_q, ssq_k = _head_sum_sq(query), _head_sum_sq(key)
         return ops.fp8_quant_attention_forward(

@@ -34,3 +34,14 @@ def is_gfx950(device=None) -> bool:
         device = torch.device(device)
         index = device.index if device.index is not None else torch.cuda.current_device()
     return "gfx950" in _arch_name(index)
+
+
+def fused_step_scales_v_per_head(D: int, in_dtype, scaling: str, Skv: int) -> bool:
+    """Mirror of qattn_fp8_quant_attention_forward's choice (csrc/qattn_api.hip quant_attention_impl, `v_block`): with head-wise scales
+    V is quantised per 64-key chunk -- no abs-max of V is read -- wherever the kernel's PV products take a chunk scale (the D = 128
+    kernel when it quantises bf16 Q itself, the templated kernel at D = 64 / 256) and a head has at most 256 chunks; only otherwise
+    does V get one scale per head, i.e. is its per-head abs-max needed."""
+    import torch
+
+    block = scaling in ("head", "head-wise") and (Skv + 63) // 64 <= 256 and (D != 128 or in_dtype == torch.bfloat16)
+    return not block

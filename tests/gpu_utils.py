@@ -48,7 +48,8 @@ def fused_step_uses_block_v(D, scaling, dtype, Skv) -> bool:
     """Mirror of qattn_fp8_quant_attention_forward's choice (csrc/qattn_api.hip): block-scaled V with head-wise scales where the
     kernel's PV products take a chunk scale -- the hand-scheduled D = 128 kernel when it quantises bf16 Q itself, the templated
     kernel at D = 64 / 256 -- and a head has at most 256 chunks; everywhere else V has one scale per head."""
-    return scaling in ("head", "head-wise") and (Skv + 63) // 64 <= 256 and (D != 128 or dtype == torch.bfloat16)
+    from quantumattention_amd.utils.checks import fused_step_scales_v_per_head
+    return scaling in ("head", "head-wise") and not fused_step_scales_v_per_head(D, dtype, scaling, Skv)
 
 
 def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfloat16, scaling="head", causal=False,

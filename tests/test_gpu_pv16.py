@@ -139,6 +139,22 @@ def test_fused_step_attends_the_16bit_v_on_rows_that_see_few_keys(S, D):
         assert mx_nc < _tol(ref_nc), mx_nc
 
 
+@pytest.mark.parametrize("D", [128, 64, 256])
+def test_causal_call_with_more_rows_than_keys_and_few_keys_runs_every_block_on_the_16bit_v(D):
+    """causal Sq > Skv with Skv < 1024 -- no block sees 1024 keys, so EVERY block is early (pv16_early_blocks), on every head
+    dim: the templated kernel's launcher used to clamp its early rows by the key count and left the later rows on one-term fp8 P."""
+    torch.manual_seed(D)
+    B, H, Sq, Skv = 1, 2, 1500, 600
+    q = torch.randn(B, H, Sq, D, dtype=torch.bfloat16, device="cuda")
+    k, v = (torch.randn(B, H, Skv, D, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    got = out_to_f32(qa.fp8_attn_func(q, k, v, is_causal=True))
+    ref16 = oracle.attention_forward(q8, k8, bits16(v), oracle.FMT_E4M3, oracle.FMT_E4M3, oracle.FMT_BF16, sq, sk, None, causal=True)
+    mx, _ = err_stats(got, ref16)
+    assert mx < _tol(ref16), mx
+
+
 def test_16bit_v_mode_argument_errors():
     q, k, v = (torch.randn(1, 2, 128, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
     q8, sq = _native.quant_fp8(q)
