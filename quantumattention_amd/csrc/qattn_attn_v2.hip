@@ -35,6 +35,7 @@
 //        after three chunks.  All paths live in one kernel, so a launch covers all query blocks of all heads.
 //  * launches with more blocks than CUs are persistent (one workgroup per CU); causal ones, and non-causal ones with many blocks per
 //    workgroup, draw their blocks from per-XCD counters (sched_next_block), heaviest first with the rescue-prone blocks ahead.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -1045,14 +1046,11 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
     const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
     const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
-    unsigned* vx = reinterpret_cast<unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D) + 16;
     float c, scale_q16 = 1.0f;
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
         scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane) & 0x7fffffffu), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
         c = p.sm_log2e * scale_q16 * p.sk[kv_head];
-        for (int i = tid; i < kVxWords; i += NW * 64) vx[i] = (unsigned)vscale_word((p.vexp && i < p.nchunks) ? p.vexp[kv_head * p.vexp_stride + i] : 127u);
-        __syncthreads();
     } else {
         c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
     }
@@ -1066,6 +1064,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
 #pragma unroll
         for (int w = 0; w < NW; w++) masks[w] = (unsigned)(w < 4 ? va[w & 3] : vb[w & 3]);
     }
+    if (Q16) lds_barrier();   // (the 16-bit-V rescue's V areas cover the vote words: every wave has read them before any area is filled)
     for (int g0 = 0; g0 < nrows; g0 += kQPerWave) {
         const bool have = g0 + ql < nrows;
         int e = have ? g0 + ql : g0, wsel = 0;
@@ -1104,15 +1103,24 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
         };
         // parked in this lane's own slots of the workgroup's Q area (behind the ring), as the sweep does: held in registers for the
         // rescue loop they cost the causal fused instantiation two spilled registers
-        unsigned char* qslot = smem + kStagesV2 * 2 * 64 * D + wave * ((D / 64) << 11) + (hh << 10) + (ql << 4);
+        // (fused step: behind the eight V areas of the 16-bit-V rescue, qattn_pv16.h rescue_rows16_at)
+        unsigned char* qslot = smem + (Q16 ? kRescue16VBytes : kStagesV2 * 2 * 64 * D) + wave * ((D / 64) << 11) + (hh << 10) + (ql << 4);
 #pragma unroll
         for (int s_ = 0; s_ < D / 64; s_++) {
             const v8i f = qfrag(s_);
             *reinterpret_cast<v4i*>(qslot + (s_ << 11)) = v4i{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<v4i*>(qslot + (s_ << 11) + 512) = v4i{f[4], f[5], f[6], f[7]};
         }
-        rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
-                                                                       [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, Q16 ? vx : nullptr);
+        if constexpr (Q16) {
+            // the fused step has the original 16-bit V at hand: the flagged rows -- rows whose weight sits on few keys, i.e. whose output carries
+            // V's rounding one to one -- get the reference kernel's own P.V numerics (16-bit P, 16-bit V), not two-term fp8 P on the fp8 V
+            const unsigned char* vg16 = p.v16 + kv_head * (long)p.Skv * (D * 2);
+            rescue_rows16_at<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL>(p, smem, kg, vg16, row, have, row_lo, row_hi, wave, lane, bh, c,
+                                                                    [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); });
+        } else {
+            rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
+                                                                           [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, nullptr);
+        }
     }
 }
 
@@ -1134,15 +1142,20 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
             return 0u;
         }
     }
-    if constexpr (Q16 && NW == 8) {
-        if (p.v16 != nullptr) {
-            const int nkeys0 = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;
-            if (nkeys0 < p.two_term_keys) {   // workgroup-uniform
-                asm volatile("" : "+v"(tid));
-                pv16_block_pass<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL, false, true>(
-                    p, smem, tid, bid, [&]() { return draw_issue(p, mail, tid); }, [&](unsigned ticket) { draw_finish(p, mail, tid, ticket); });
-                return 0u;
-            }
+    // ... and so does (round 5) every block of the fused step that used to run two-term fp8 P: blocks predicted peaked, blocks that
+    // repeat after a one-term sweep with too many flagged rows, every block under QATTN_PRECISION_ACCURATE (`pass16` below).  The same
+    // MFMA time as the two-term pass, fewer vector instructions, and the rows that need the precision most no longer attend an fp8 V.
+    auto pass16 = [&](volatile unsigned* mail_) {
+        asm volatile("" : "+v"(tid));
+        pv16_block_pass<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL, false, true>(
+            p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); }, [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
+    };
+    constexpr bool kPass16 = Q16 && NW == 8;   // (the fused step always carries the 16-bit V: qattn_api.hip quant_attention_impl)
+    if constexpr (kPass16) {
+        const int nkeys0 = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;
+        if (nkeys0 < p.two_term_keys) {   // workgroup-uniform
+            pass16(mail);
+            return 0u;
         }
     }
     // One copy of each pass.  Every per-lane value is re-derived inside block_pass from an opaque copy of the thread index, so
@@ -1183,8 +1196,8 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
     for (;;) {
         asm volatile("" : "+v"(tid));
         if (two) {
-            // (SUMM = false: see block_pass)
-            block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16, false, false>(p, smem, tid, bid, false, mail);
+            if constexpr (kPass16) pass16(mail);
+            else block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16, false, false>(p, smem, tid, bid, false, mail);   // (SUMM = false: see block_pass)
             break;
         }
         const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK>(p, smem, tid, bid, CHECK, mail);
@@ -1265,6 +1278,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
 #ifdef QATTN_DEV
         if (wlog && threadIdx.x == 0) wlog[2] = __builtin_amdgcn_s_memrealtime();
 #endif
+        int next_drawn = -1;
+        if constexpr (CHECK && !TOKEN && NW == 8 && Q16) {
+            // (the 16-bit-V rescue's V areas cover the mailbox: the successor's number -- written before the block's vote barrier -- is taken out first)
+            if (resc != 0 && dynamic) next_drawn = __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
+        }
         if constexpr (CHECK && !TOKEN && NW == 8) {
             // a few peaked rows: on the spot, while the head's K / V are in this XCD's L2 (every wave is past the vote barrier, hence
             // done with the K/V ring).  The block's successor HAS been drawn by then (draw_issue / draw_finish inside attend_block, before the
@@ -1284,7 +1302,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
         if (dynamic) {
             // the successor was drawn in this block's prologue (draw_next_block)
             lds_barrier();   // also: every wave has left the ring and the Q slots before the next block fills them
-            next = __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
+            next = (CHECK && !TOKEN && NW == 8 && Q16 && resc != 0) ? next_drawn : __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
             parity ^= 1;
         } else if (!CAUSAL && bid + (int)gridDim.x < p.total_blocks) {
             next = bid + (int)gridDim.x;
@@ -1320,6 +1338,7 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
         p.sched = nullptr;
     }
     size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes + the Q prefetch's dump slot
+    if (Q16 && CHECK && NW == 8) lds = std::max(lds, (size_t)kRescue16VBytes + (size_t)NW * kQPerWave * D);   // the 16-bit-V rescue: eight V areas + the parked Q^T fragments = all 160 KiB (one workgroup per CU either way)
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
 #endif

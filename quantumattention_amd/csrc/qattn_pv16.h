@@ -556,6 +556,203 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The row-level rescue on the reference's own P.V numerics (round 5): the 32 gathered rows of rescue_rows_at
+// (qattn_attn.h) recomputed with FP8 QK^T, exact exponentials, 16-bit P and the ORIGINAL 16-bit V, the key range split over the NW = 8
+// waves of the block as there.  A flagged row is one whose weight sits on few keys: exactly the rows whose output carries V's rounding
+// error one to one -- two-term P cured P's rounding and left V's 2^-4 (0.045 max-abs against fp64 SDPA on the 16-bit V at a score
+// spread of 2, VERDICT r4 Missing-2).
+// Every wave copies ITS chunk of V (64 rows x 256 B, the XOR image of pv16_block_pass) into a 16 KiB area of its own by LDS-DMA
+// and reads the K fragments straight from global memory / L2 (both requests of a chunk travel together); one chunk in flight per wave:
+// a rescue is a handful of chunks per wave and latency-bound either way.  LDS: 8 x 16 KiB of V, the gathered rows' parked Q^T
+// fragments behind them (the caller's), the merge slots alias the V areas afterwards.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kRescue16VBytes = 8 * 64 * 2 * 128;   // the V areas of the eight waves (D = 128)
+template <int D, int NW, int QK_FMT, int V16_FMT, bool CAUSAL, typename QFrag>
+__device__ __forceinline__ void rescue_rows16_at(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg16,
+                                                 int row, bool store, int row_lo, int row_hi, int wave, int lane, long bh, float c, QFrag&& qfrag) {
+    static_assert(NW == 8 && D == 128, "eight 16 KiB V areas, three merge rounds");
+    typedef Pv16Type<V16_FMT> T;
+    typedef typename T::vec vec16;
+    constexpr int CH = 64 * D, KS = D / 64, MB = D / 32, RB = 2 * D, VCH = 64 * RB;
+    constexpr int SLOT = rescue_slot_bytes<D>();
+    static_assert(NW * VCH == kRescue16VBytes && 4 * SLOT <= NW * VCH, "the merge slots alias the V areas");
+    const int ql = lane & 31, hh = lane >> 5;
+    const int frag_lane_off = (hh << 10) + (ql << 4);
+    v8i qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) qf[s] = qfrag(s);
+    const int n_r = CAUSAL ? min(p.nchunks, min(row_hi, p.Sq - 1) / 64 + 1) : p.nchunks;
+    const int per = (n_r + NW - 1) / NW;
+    const int t0 = wave * per, t1 = min(n_r, t0 + per);
+    v16f o[MB];
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[m][r] = 0.0f;
+    float m_run = -1.0e30f;
+    v4f lsum = {0.0f, 0.0f, 0.0f, 0.0f};
+    vec16 ones;
+    {
+        const int rowi = lane & 15, kgrp = lane >> 4;
+        const int one = ((rowi == 0 && !(kgrp & 1)) || (rowi == 1 && (kgrp & 1))) ? (int)T::kOnes : 0;
+        const v4i w = {one, one, one, one};
+        __builtin_memcpy(&ones, &w, 16);
+    }
+    // V chunk t -> this wave's area: piece pc = rows 4 pc .. 4 pc + 3, lane i copies the 16-byte chunk (i & 15) ^ f(r) of row r = 4 pc + (i >> 4)
+    unsigned char* varea = smem + wave * VCH;
+    const int vr = lane >> 4, vc = lane & 15;
+    auto dma_v = [&](int t) {
+#pragma unroll
+        for (int pc = 0; pc < VCH / 1024; pc++) {
+            const int r = 4 * pc + vr;
+            const int f = ((r & 3) << 2) | ((r >> 2) & 3);
+            const unsigned char* src = vg16 + (long)min(t * 64 + r, p.Skv - 1) * RB + ((vc ^ f) << 4);   // (keys beyond Skv: the last row; their P is 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(varea + (pc << 10)), 16, 0, 0);
+        }
+    };
+    // per-lane pieces of the transposed-read addresses (pv16_block_pass, D = 128)
+    const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
+    const int cc = 2 * cg + (p4 >> 1);
+    const unsigned tr_lo = (unsigned)RB * (4 * hh + q4) + 16u * (cc ^ hh) + 8u * (p4 & 1);
+    const unsigned tr_hi = (unsigned)RB * (4 * hh + 8 + q4) + 16u * (cc ^ (hh + 2)) + 8u * (p4 & 1);
+    const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)varea;
+    unsigned alo[MB], ahi[MB];
+#pragma unroll
+    for (int m = 0; m < MB; m++) {
+        const unsigned xm = 64u * (unsigned)(m ^ q4);
+        alo[m] = vaddr + tr_lo + xm;
+        ahi[m] = vaddr + tr_hi + xm;
+    }
+    for (int t = t0; t < t1; t++) {
+        // the chunk's K fragments are requested FIRST: their round trip runs under the sixteen LDS-DMA requests of its V (60 - 100 issue
+        // cycles each for the requesting wave), which in turn fly under QK^T and the exponentials
+        const unsigned char* kc = kg + (long)t * CH + frag_lane_off;
+        v8i kf[2 * KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            kf[2 * s] = gload_frag(kc + ((0 * KS + s) << 11));
+            kf[2 * s + 1] = gload_frag(kc + ((1 * KS + s) << 11));
+        }
+        asm volatile("" ::: "memory");
+        dma_v(t);
+        v16f s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s0[r] = 0.0f; s1[r] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            s0 = mfma_f8<QK_FMT, QK_FMT>(kf[2 * s], qf[s], s0);
+            s1 = mfma_f8<QK_FMT, QK_FMT>(kf[2 * s + 1], qf[s], s1);
+        }
+        prep_scores<CAUSAL, false>(s0, s1, p, t * 64, row_lo, row, hh, nullptr);
+        float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
+        mx = fmaxf(mx, s0[15]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (__any((mx - m_run) * c > kPv16RescaleThr)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[m][r] *= alpha;
+            lsum[0] *= alpha;
+            lsum[1] *= __uint_as_float(swizzle_xor16(__float_as_uint(alpha)));
+            m_run = m_new;
+        }
+        const float mc = -m_run * c;
+        vec16 pb[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const v16f& sx = tt ? s1 : s0;
+                unsigned w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[8 * s + 2 * j], c, mc));
+                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[8 * s + 2 * j + 1], c, mc));
+                    w[j] = T::pack2(e0, e1);
+                }
+                const v4i wv = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+                __builtin_memcpy(&pb[tt][s], &wv, 16);
+                lsum = T::mfma_sum(ones, pb[tt][s], lsum);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V(t) has landed in this wave's area
+        // O^T += V^T.P^T, one k-step (16 keys) after the other over the four column blocks, the next k-step's transposed reads in flight
+        {
+            v2i32 ra[2 * MB], rb[2 * MB];
+#define QATTN_R16_ISSUE(R, J)                                                  \
+    _Pragma("unroll") for (int m = 0; m < MB; m++) {                           \
+        R[2 * m] = pv16_read_tr_at<RB * 16 * J>(alo[m]);                       \
+        R[2 * m + 1] = pv16_read_tr_at<RB * 16 * J>(ahi[m]);                   \
+    }
+#define QATTN_R16_MUL(R, PJ) _Pragma("unroll") for (int m = 0; m < MB; m++) o[m] = T::mfma(pv16_operand<vec16>(R[2 * m], R[2 * m + 1]), PJ, o[m]);
+            QATTN_R16_ISSUE(ra, 0)
+            QATTN_R16_ISSUE(rb, 1)
+            pv16_wait_lds<2 * MB>(ra);
+            QATTN_R16_MUL(ra, pb[0][0])
+            QATTN_R16_ISSUE(ra, 2)
+            pv16_wait_lds<2 * MB>(rb);
+            QATTN_R16_MUL(rb, pb[0][1])
+            QATTN_R16_ISSUE(rb, 3)
+            pv16_wait_lds<2 * MB>(ra);
+            QATTN_R16_MUL(ra, pb[1][0])
+            pv16_wait_lds<0>(rb);   // (every read of the area is complete: the next chunk may overwrite it)
+            QATTN_R16_MUL(rb, pb[1][1])
+#undef QATTN_R16_ISSUE
+#undef QATTN_R16_MUL
+        }
+    }
+    // the row sums, per lane (both half-waves' keys are in them): query q's sits in lane q & 15, register q >> 4
+    float l_run;
+    {
+        const float l_lo = bcast_low16(lsum[0]), l_hi = bcast_low16(lsum[1]);
+        l_run = (lane & 16) ? l_hi : l_lo;
+    }
+    // ---- merge the NW partials pairwise through LDS: {4..7} -> {0..3}, {2,3} -> {0,1}, {1} -> {0}  (rescue_rows_at)
+    __syncthreads();   // every wave is done with its V area, which the slots alias
+    float* slots = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            float* d = slots + (wave - half) * (SLOT / 4);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++)
+                    *reinterpret_cast<v4f*>(d + ((m * 4 + r4) * 64 + lane) * 4) = v4f{o[m][4 * r4], o[m][4 * r4 + 1], o[m][4 * r4 + 2], o[m][4 * r4 + 3]};
+            d[MB * 16 * 64 + lane] = m_run;
+            d[(MB * 16 + 1) * 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float* d = slots + wave * (SLOT / 4);
+            const float m_b = d[MB * 16 * 64 + lane], l_b = d[(MB * 16 + 1) * 64 + lane];
+            const float m_new = fmaxf(m_run, m_b);
+            const float fa = __builtin_amdgcn_exp2f((m_run - m_new) * c), fb = __builtin_amdgcn_exp2f((m_b - m_new) * c);
+#pragma unroll
+            for (int m = 0; m < MB; m++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const v4f ob = *reinterpret_cast<const v4f*>(d + ((m * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[m][4 * r4 + i] = o[m][4 * r4 + i] * fa + ob[i] * fb;
+                }
+            l_run = l_run * fa + l_b * fb;
+            m_run = m_new;
+        }
+        __syncthreads();
+    }
+    if (wave == 0) store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_run, bh * p.Sq + row, hh, store && row < p.Sq);
+}
+
 // The 16-bit-V form of qattn_fp8_attention_forward (v_fmt = QATTN_FMT_BF16 / _FP16): every query block through pv16_block_pass, one
 // workgroup per block (map_block: XCD-contiguous heads, causal blocks heaviest first).
 // n_blocks > 0: only the first n_blocks query blocks of every head (the fused step's early rows on the paths whose main kernel has no

@@ -52,6 +52,28 @@ def fused_step_uses_block_v(D, scaling, dtype, Skv) -> bool:
     return scaling in ("head", "head-wise") and not fused_step_scales_v_per_head(D, dtype, scaling, Skv)
 
 
+class FusedRef(np.ndarray):
+    """The reference of the FUSED step: the array itself is the mixed oracle (fp64 SDPA with the block-scaled fp8 V; the original 16-bit V
+    on the rows of the early blocks), `.alt` is fp64 SDPA with the original 16-bit V on EVERY row.  Since round 5 the D = 128 kernel
+    recomputes the rows its statistics flag (and the blocks it used to run with two-term P) on the 16-bit V -- the reference kernel's own
+    numerics, csrc/qattn_pv16.h -- and which rows those are is the kernel's data-dependent decision: a row must meet the bound against
+    ONE of the two (err_stats takes, per row, the closer).  Slicing keeps the pair aligned."""
+
+    def __new__(cls, main, alt):
+        obj = np.asarray(main).view(cls)
+        obj.alt = np.asarray(alt)
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.alt = getattr(obj, "alt", None)
+
+    def __getitem__(self, idx):
+        out = super().__getitem__(idx)
+        if isinstance(out, FusedRef):
+            out.alt = self.alt[idx] if self.alt is not None and self.alt.shape == np.asarray(self).shape else None
+        return out
+
+
 def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfloat16, scaling="head", causal=False,
                         sm_scale=0.0, return_lse=False, v_block=False, q_offset=0, v16_early=None, fused=False):
     """O3 of SURVEY.md §8c: fp64 SDPA on the same quantised q, k AND the build's quantised v (v_block: the fused step's
@@ -81,9 +103,18 @@ def oracle_for_fp8_path(q8b, k8b, v16b, sq, sk, *, fp8="e4m3", v_dtype=torch.bfl
                                            scale_mode=scaling, causal=causal, sm_scale=sm_scale, return_lse=False, q_offset=q_offset)
             out = res[0] if return_lse else res
             out[:, :, :n_early] = r16
+    if fused:   # the 16-bit-V reference beside the mixed one (FusedRef)
+        alt = oracle.attention_forward(q8b, k8b, v16b, FMT[fp8], FMT[fp8], fmt16(v_dtype), sq, sk, None, scale_mode=scaling, causal=causal,
+                                       sm_scale=sm_scale, return_lse=False, q_offset=q_offset)
+        res = (FusedRef(res[0], alt),) + tuple(res[1:]) if return_lse else FusedRef(res, alt)
     return res
 
 
 def err_stats(got: np.ndarray, ref: np.ndarray):
-    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    """(max-abs, rmse) of got against ref; against a FusedRef, per row (last axis) against the closer of its two references."""
+    d = np.abs(got.astype(np.float64) - np.asarray(ref).astype(np.float64))
+    alt = getattr(ref, "alt", None)
+    if alt is not None and alt.shape == d.shape:
+        d2 = np.abs(got.astype(np.float64) - alt.astype(np.float64))
+        d = np.where(d2.max(axis=-1, keepdims=True) < d.max(axis=-1, keepdims=True), d2, d)
     return float(d.max()), float(np.sqrt((d ** 2).mean()))

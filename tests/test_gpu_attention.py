@@ -257,7 +257,8 @@ def test_causal_block_order_visits_every_block_once(B, H, S):
     """Causal AUTO launches take a head's query blocks longest first, except that the blocks right above the two-term line go
     before everything else (qattn_attn.h causal_order), persistent with a dynamic hand-out when there are more blocks than
     CUs.  Whatever the order, every block is computed exactly once: no row stays unwritten, and the result agrees with the
-    ACCURATE launch (every block two-term, no rescues) within the one-term budget."""
+    ACCURATE launch (since round 5: every block on the 16-bit V with 16-bit P, no rescues) within the one-term budget plus what the fp8
+    V of the one-term rows costs against the 16-bit V."""
     torch.manual_seed(S)
     q, k, v = (torch.randn(B, H, S, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))
     with qa.config.patch({"attention.precision": "accurate"}):
@@ -269,7 +270,7 @@ def test_causal_block_order_visits_every_block_once(B, H, S):
             out = qa.fp8_attn_func(q, k, v, is_causal=True)
         assert torch.isfinite(out).all(), precision
         # (FAST has no budget on rows that see few keys; AUTO keeps every row within it)
-        bound = 0.02 if precision == "auto" else 0.25
+        bound = 0.04 if precision == "auto" else 0.25
         assert (out.float() - ref.float()).abs().max().item() < bound, precision
 
 
