@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kTeamThreads) void quant_team_kernel(const OneReadJ
 #pragma unroll
                 for (int u = 0; u < UVEC; u++) {
                     const int vec = u * 64 + lane;
-                    const int2 q8 = IN_FMT == QATTN_FMT_BF16 ? quant8<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale, rinv) : quant8_exact_call<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale);   // (fp16: the exact sequence, out of line)
+                    const int2 q8 = quant8<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale, rinv);   // (fp16: the exact sequence, out of line)
                     const int o = kfrag_offset<D>(vec / VPR, (vec % VPR) * 8);   // key < 32: the t = 0 half of the image
                     *reinterpret_cast<int2*>(ub + o + ((o >> 9) << 4)) = q8;
                 }
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kTeamThreads) void quant_team_kernel(const OneReadJ
 #pragma unroll
                 for (int u = 0; u < UVEC; u++) {
                     const int vec = u * 64 + lane;
-                    const int2 q8 = IN_FMT == QATTN_FMT_BF16 ? quant8<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale, rinv) : quant8_exact_call<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale);
+                    const int2 q8 = quant8<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale, rinv);
                     unsigned char* dst = ub + (vec / VPR) * VSTRIDE + (vec % VPR) * 8;
                     *reinterpret_cast<int*>(dst) = q8.x;
                     *reinterpret_cast<int*>(dst + 4) = q8.y;
