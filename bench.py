@@ -584,8 +584,8 @@ def run_rank(args):
             except Exception as exc:
                 print(f"[bench] 16-bit-V mode sample skipped: {exc}", file=sys.stderr)
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
-            def extra(Bx, Hx, Sx, causal, fp8, n):
-                qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+            def extra(Bx, Hx, Sx, causal, fp8, n, dtype=torch.bfloat16):
+                qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=dtype, device="cuda") for _ in range(3))
                 fn = lambda: qa.fp8_attn_func(qx, kx, vx, is_causal=causal)
                 with qa.config.patch({"attention.fp8_format": fp8, "attention.precision": args.precision}):
                     ms = event_time(fn, n)
@@ -595,12 +595,15 @@ def run_rank(args):
                         "attn_frac_of_peak": None if not ams else fl / (ams * 1e-3) / 1e12 / FP8_PEAK_TFLOPS}
             if (B, H, S, D) == (4, 32, 4096, 128) and not args.causal:
                 line["c3_causal_B4_H32_S4096"] = extra(4, 32, 4096, True, "e4m3", 20)
+                # the same two steps from fp16 inputs (the reference builds and tests both 16-bit types, tk/attention.py:17-29, tests/test_interface.py:67,96)
+                line["c2_fp16"] = extra(4, 32, 4096, False, "e4m3", 20, dtype=torch.float16)
+                line["c3_fp16"] = extra(4, 32, 4096, True, "e4m3", 20, dtype=torch.float16)
                 line["c5_causal_e5m2_B4_H40_S16384"] = extra(4, 40, 16384, True, "e5m2", 5)
                 # the reference's own benchmark grid (tests/test_interface.py:95-102,141-156): B16 H16 S8192, D in {64,128,256}
                 ref_grid = {}
-                for Dx in (64, 128, 256):
+                for Dx, dtx in [(d_, t_) for t_ in (torch.bfloat16, torch.float16) for d_ in (64, 128, 256)]:
                     for causal in (False, True):
-                        qx, kx, vx = (torch.randn(16, 16, 8192, Dx, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+                        qx, kx, vx = (torch.randn(16, 16, 8192, Dx, dtype=dtx, device="cuda") for _ in range(3))
                         fn = lambda: qa.fp8_attn_func(qx, kx, vx, is_causal=causal)
                         with qa.config.patch({"attention.fp8_format": "e4m3", "attention.precision": args.precision}):
                             for _ in range(10):
@@ -608,11 +611,11 @@ def run_rank(args):
                             ms = event_time(fn, 5)
                             ams = attn_in_step(fn, 3)
                         fl = flops(16, 16, 8192, 8192, Dx, causal)
-                        ref_grid[f"D{Dx}_{'causal' if causal else 'full'}"] = {
+                        ref_grid[f"D{Dx}_{'causal' if causal else 'full'}{'_fp16' if dtx == torch.float16 else ''}"] = {
                             "ms_per_step": ms, "attn_kernel_ms": ams, "step_TFLOPs": fl / (ms * 1e-3) / 1e12,
                             "attn_frac_of_peak": None if not ams else fl / (ams * 1e-3) / 1e12 / FP8_PEAK_TFLOPS}
                         del qx, kx, vx
-                line["reference_bench_shape"] = {"shape": "B16 H16 S8192, bf16 in/out, e4m3, head-wise (tests/test_interface.py:95-102)", **ref_grid}
+                line["reference_bench_shape"] = {"shape": "B16 H16 S8192, bf16 (and `_fp16`: fp16) in/out, e4m3, head-wise (tests/test_interface.py:95-102)", **ref_grid}
                 # distance to the reference's own semantics (V and P stay 16-bit there), per config, on a head slice
                 acc = {}
                 with qa.config.patch({"attention.fp8_format": "e4m3", "attention.precision": args.precision}):

@@ -339,14 +339,14 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
 
-// true when the attention kernel can quantise Q itself (hand-scheduled D = 128 kernel, head-wise scales, bf16 inputs,
-// byte-exponential path): then the pre-pass skips Q's payload (one read and one write of Q less).
+// true when the attention kernel can quantise Q itself (hand-scheduled D = 128 kernel, head-wise scales, bf16 or -- since round 5 -- fp16
+// inputs, byte-exponential path): then the pre-pass skips Q's payload (one read and one write of Q less).
 bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
 #ifdef QATTN_DEV
     const DevEnv& e = dev_env();
     if (e.variant != 2 || e.exact_exp || e.waves != 8 || e.no_q_fusion || getenv("QATTN_NO_Q_FUSION")) return false;   // (also per call: tools/ab.py variants)
 #endif
-    return D == 128 && in_fmt == QATTN_FMT_BF16 && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
+    return D == 128 && (in_fmt == QATTN_FMT_BF16 || in_fmt == QATTN_FMT_FP16) && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
 }
 
 }  // namespace

@@ -864,7 +864,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
 // but it breaks the bound on very peaked rows (q x 3 at S = 4096: 0.022): thousands of keys 15 binades below the row's top key flush to
 // zero in fp8; their V rows average out of the numerator, but their weights ARE 0.5 .. 1 % of the denominator, and a denominator that
 // drops them too rescales the output by that much.  The exact fp32 sum of the un-rounded exponentials stays.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16, bool NEFF = false, bool SUMM = false>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool Q16, bool NEFF = false, bool SUMM = false, int IN16 = QATTN_FMT_BF16>
 __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, bool check_peaked, volatile unsigned* mail = nullptr) {
     constexpr int CH = 64 * D;      // bytes of one K (or V) chunk
     constexpr int STAGE = 2 * CH;   // K chunk + V chunk
@@ -934,7 +934,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
         if (tid < kVxWords) vx[tid] = (unsigned)vscale_word(vxw);
         const unsigned am = max(max(a0, a1), max(a2, a3)) & 0x7fffffffu;   // (a caller-supplied abs-max enters by magnitude)
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(wave_allmax_u32(am)), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        scale_q16 = make_scale(__uint_as_float(wave_allmax_u32(am)), inv_qmax, p.q_numerics, IN16);
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q16;
     }
     // pre-quantised Q: the lane's 32-byte pieces, requested here for the same reason
@@ -966,7 +966,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
             for (int s = 0; s < KS; s++) {
                 int2 w[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(qvalid ? rawq[Q16 ? s : 0][i] : make_uint4(0, 0, 0, 0), scale_q16, rinv);
+                for (int i = 0; i < 4; i++) w[i] = quant8<IN16, QK_FMT>(qvalid ? rawq[Q16 ? s : 0][i] : make_uint4(0, 0, 0, 0), scale_q16, rinv);
                 *reinterpret_cast<v4i*>(qbuf + (s << 11)) = v4i{w[0].x, w[0].y, w[1].x, w[1].y};
                 *reinterpret_cast<v4i*>(qbuf + (s << 11) + 512) = v4i{w[2].x, w[2].y, w[3].x, w[3].y};
             }
@@ -1033,7 +1033,7 @@ __device__ __forceinline__ int select_bit(unsigned m, int e) {
     return pos;
 }
 
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool Q16>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool Q16, int IN16 = QATTN_FMT_BF16>
 __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, int nrows) {   // nrows: set bits of the block's vote words
     constexpr int CH = 64 * D;
     const int lane = tid & 63;
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     float c, scale_q16 = 1.0f;
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane) & 0x7fffffffu), inv_qmax, p.q_numerics, QATTN_FMT_BF16);
+        scale_q16 = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane) & 0x7fffffffu), inv_qmax, p.q_numerics, IN16);
         c = p.sm_log2e * scale_q16 * p.sk[kv_head];
     } else {
         c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
@@ -1091,7 +1091,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
                 for (int i = 0; i < 4; i++) {
                     uint4 raw = qp[i];
                     if (!qvalid) raw = make_uint4(0, 0, 0, 0);
-                    w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw, scale_q16, rinv);
+                    w[i] = quant8<IN16, QK_FMT>(raw, scale_q16, rinv);
                 }
                 return v8i{w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y, w[3].x, w[3].y};
             } else {
@@ -1115,7 +1115,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
             // the fused step has the original 16-bit V at hand: the flagged rows -- rows whose weight sits on few keys, i.e. whose output carries
             // V's rounding one to one -- get the reference kernel's own P.V numerics (16-bit P, 16-bit V), not two-term fp8 P on the fp8 V
             const unsigned char* vg16 = p.v16 + kv_head * (long)p.Skv * (D * 2);
-            rescue_rows16_at<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL>(p, smem, kg, vg16, row, have, row_lo, row_hi, wave, lane, bh, c,
+            rescue_rows16_at<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, kg, vg16, row, have, row_lo, row_hi, wave, lane, bh, c,
                                                                     [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); });
         } else {
             rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
 // One 256-row block: a block whose rows are predicted peaked (predicted_r) starts two-term; a one-term pass that finds too
 // many peaked rows loops back into the same two-term code.
 // Returns the bit mask of the block's 32-row groups (waves) that still need rescue_pass (0: none; CHECK launches only).
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16, bool CHECK>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL, bool Q16, bool CHECK, int IN16 = QATTN_FMT_BF16>
 __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char* smem, int bid, int tid, volatile unsigned* mail) {   // tid: an opaque copy of threadIdx.x; mail: draw_next_block
     int head, qb;
     map_block(p, bid, p.nqb, CAUSAL, head, qb);
@@ -1147,7 +1147,7 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
     // MFMA time as the two-term pass, fewer vector instructions, and the rows that need the precision most no longer attend an fp8 V.
     auto pass16 = [&](volatile unsigned* mail_) {
         asm volatile("" : "+v"(tid));
-        pv16_block_pass<D, NW, QK_FMT, QATTN_FMT_BF16, CAUSAL, false, true>(
+        pv16_block_pass<D, NW, QK_FMT, IN16, CAUSAL, false, true>(
             p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); }, [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
     };
     constexpr bool kPass16 = Q16 && NW == 8;   // (the fused step always carries the 16-bit V: qattn_api.hip quant_attention_impl)
@@ -1197,10 +1197,10 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
         asm volatile("" : "+v"(tid));
         if (two) {
             if constexpr (kPass16) pass16(mail);
-            else block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16, false, false>(p, smem, tid, bid, false, mail);   // (SUMM = false: see block_pass)
+            else block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, true, false, 0, Q16, false, false, IN16>(p, smem, tid, bid, false, mail);   // (SUMM = false: see block_pass)
             break;
         }
-        const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK>(p, smem, tid, bid, CHECK, mail);
+        const int r = block_pass<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, false, BYTE, ABL, Q16, CHECK, false, IN16>(p, smem, tid, bid, CHECK, mail);
         mail = nullptr;   // (a repeated block has drawn its successor already)
         if (r == 0) break;
         if (r != kPassRedo) {   // a few peaked groups (every wave is past the vote barrier, hence done with the K/V ring)
@@ -1230,7 +1230,7 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
 // other XCDs (S = 8192: -4 %, S = 16384: -2...3 % against one workgroup per block; S = 4096: equal).  A static stride over that
 // order was 6 % slower and balanced pairs of blocks 3-10 % slower in round 2.  Without the state (a caller without a
 // workspace) causal launches use one workgroup per block.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false, bool CHECK = false>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false, bool CHECK = false, int IN16 = QATTN_FMT_BF16>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // two words behind the waves' vote words carry a block number / queue item from thread 0 to the workgroup
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
 #endif
         {
             QATTN_PARAMS();
-            resc = run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK>(p, smem, bid, tid, dynamic ? bcast + parity : nullptr);
+            resc = run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK, IN16>(p, smem, bid, tid, dynamic ? bcast + parity : nullptr);
         }
 #ifdef QATTN_DEV
         if (wlog && threadIdx.x == 0) wlog[2] = __builtin_amdgcn_s_memrealtime();
@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
             if (resc != 0) {
                 QATTN_PARAMS();
                 asm volatile("" : "+v"(tid));
-                rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16>(p, smem, tid, bid, resc);
+                rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16, IN16>(p, smem, tid, bid, resc);
             }
         }
 #ifdef QATTN_DEV
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
 #undef QATTN_PARAMS
 }
 
-template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16, bool CHECK>
+template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16, bool CHECK, int IN16 = QATTN_FMT_BF16>
 static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     AttnParams p = pin;
     p.total_blocks = p.B * p.Hq * p.nqb;
@@ -1350,7 +1350,7 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
         return QATTN_OK;
     }
 #endif
-    if constexpr (FMT == QATTN_FMT_E4M3 && Q16 && BYTE && NW == 8 && !TOKEN) {
+    if constexpr (FMT == QATTN_FMT_E4M3 && Q16 && BYTE && NW == 8 && !TOKEN && IN16 == QATTN_FMT_BF16) {
         if (p.stamp_buf) {   // measurement entry: the same kernel with the two clock stamps per wave
             auto kern1 = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 1024, Q16, CHECK>;
             if (hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
@@ -1359,15 +1359,25 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
         }
     }
     if (p.stamp_buf) return QATTN_ERR_UNSUPPORTED_FMT;   // (only the fused e4m3 step has a stamped instantiation)
-    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 0, Q16, CHECK>;
+    auto kern = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 0, Q16, CHECK, IN16>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
     return QATTN_OK;
 }
-template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16 = false>
+template <int D, int NW, int FMT, bool CAUSAL, bool TOKEN, bool BYTE, bool Q16 = false, int IN16 = QATTN_FMT_BF16>
 static int launch_attn_v2_one(const AttnParams& p, hipStream_t st) {
-    return p.peak_r0 > 0.0f ? launch_attn_v2_chk<D, NW, FMT, CAUSAL, TOKEN, BYTE, Q16, true>(p, st)
-                            : launch_attn_v2_chk<D, NW, FMT, CAUSAL, TOKEN, BYTE, Q16, false>(p, st);
+    return p.peak_r0 > 0.0f ? launch_attn_v2_chk<D, NW, FMT, CAUSAL, TOKEN, BYTE, Q16, true, IN16>(p, st)
+                            : launch_attn_v2_chk<D, NW, FMT, CAUSAL, TOKEN, BYTE, Q16, false, IN16>(p, st);
+}
+
+// The fused step from fp16 inputs (round 5): the same kernels with IN16 = QATTN_FMT_FP16 -- in-kernel Q quantisation (quant8's fp16 fast
+// path), block-scaled V, 16-bit-V passes on fp16 V and P.  Instantiated in translation units of their own (build.py: -DQATTN_ONLY_IN16=3
+// beside -DQATTN_ONLY_FMT; the other units compile with QATTN_ONLY_IN16=2 and only call the entry points).
+int launch_attn_v2_f16_e4m3(const AttnParams& p, int causal, hipStream_t st);
+int launch_attn_v2_f16_e5m2(const AttnParams& p, int causal, hipStream_t st);
+template <int FMT, bool CAUSAL>
+static int launch_attn_v2_f16(const AttnParams& p, hipStream_t st) {
+    return FMT == QATTN_FMT_E4M3 ? launch_attn_v2_f16_e4m3(p, CAUSAL ? 1 : 0, st) : launch_attn_v2_f16_e5m2(p, CAUSAL ? 1 : 0, st);
 }
 
 template <int D, int NW, int FMT, bool CAUSAL>
@@ -1403,7 +1413,10 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     if (p.lds_pad == -1) byte_exp = true;  // debugging: LSE from the byte-exponential pass (QATTN_V2_LDS=-1)
 #endif
     if (scale_mode == QATTN_SCALE_TOKEN) return QATTN_ERR_UNSUPPORTED_FMT;  // routed to the templated kernel (attn_v2_covers)
-    if (p.q16 != nullptr) return launch_attn_v2_one<D, 8, FMT, CAUSAL, false, true, true>(p, st);  // fused step: byte path only (qattn_api.hip)
+    if (p.q16 != nullptr) {   // fused step: byte path only (qattn_api.hip); its 16-bit input type is the output's
+        if (p.out_fmt == QATTN_FMT_FP16) return launch_attn_v2_f16<FMT, CAUSAL>(p, st);   // (a translation unit of its own, below)
+        return launch_attn_v2_one<D, 8, FMT, CAUSAL, false, true, true>(p, st);
+    }
     return byte_exp ? launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true>(p, st) : launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false>(p, st);
 }
 
@@ -1415,11 +1428,26 @@ static int launch_attn_v2_fmt(const AttnParams& p, int causal, int scale_mode, h
 #endif
     return causal ? launch_attn_v2_t<128, 8, FMT, true>(p, scale_mode, st) : launch_attn_v2_t<128, 8, FMT, false>(p, scale_mode, st);
 }
+#if !defined(QATTN_ONLY_IN16) || QATTN_ONLY_IN16 == 2
 #if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 0
 int launch_attn_v2_e4m3(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E4M3>(p, causal, scale_mode, st); }
 #endif
 #if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 1
 int launch_attn_v2_e5m2(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E5M2>(p, causal, scale_mode, st); }
+#endif
+#endif
+#if !defined(QATTN_ONLY_IN16) || QATTN_ONLY_IN16 == 3
+template <int FMT>
+static int launch_attn_v2_f16_fmt(const AttnParams& p, int causal, hipStream_t st) {
+    return causal ? launch_attn_v2_one<128, 8, FMT, true, false, true, true, QATTN_FMT_FP16>(p, st)
+                  : launch_attn_v2_one<128, 8, FMT, false, false, true, true, QATTN_FMT_FP16>(p, st);
+}
+#if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 0
+int launch_attn_v2_f16_e4m3(const AttnParams& p, int causal, hipStream_t st) { return launch_attn_v2_f16_fmt<QATTN_FMT_E4M3>(p, causal, st); }
+#endif
+#if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 1
+int launch_attn_v2_f16_e5m2(const AttnParams& p, int causal, hipStream_t st) { return launch_attn_v2_f16_fmt<QATTN_FMT_E5M2>(p, causal, st); }
+#endif
 #endif
 
 }  // namespace qattn

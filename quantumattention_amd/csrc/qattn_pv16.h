@@ -202,7 +202,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
         const float scale_q = make_scale(__uint_as_float(max_partials(p.q_amax_part + bh * p.amax_stride, p.amax_n, lane) & 0x7fffffffu), inv_qmax,
-                                         p.q_numerics, QATTN_FMT_BF16);
+                                         p.q_numerics, V16_FMT);   // (the fused step's q, k, v share one 16-bit type)
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q;   // (the block that holds row 0 writes the head's scale, whichever pass runs it)
         const float rinv = 1.0f / scale_q;
         const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
@@ -213,7 +213,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
             for (int i = 0; i < 4; i++) {
                 uint4 raw = qp[s * 8 + i];
                 if (!qvalid) raw = make_uint4(0, 0, 0, 0);
-                w[i] = quant8<QATTN_FMT_BF16, QK_FMT>(raw, scale_q, rinv);
+                w[i] = quant8<V16_FMT, QK_FMT>(raw, scale_q, rinv);
             }
             qf[s] = v8i{w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y, w[3].x, w[3].y};
         }

@@ -38,10 +38,9 @@ def is_gfx950(device=None) -> bool:
 
 def fused_step_scales_v_per_head(D: int, in_dtype, scaling: str, Skv: int) -> bool:
     """Mirror of qattn_fp8_quant_attention_forward's choice (csrc/qattn_api.hip quant_attention_impl, `v_block`): with head-wise scales
-    V is quantised per 64-key chunk -- no abs-max of V is read -- wherever the kernel's PV products take a chunk scale (the D = 128
-    kernel when it quantises bf16 Q itself, the templated kernel at D = 64 / 256) and a head has at most 256 chunks; only otherwise
-    does V get one scale per head, i.e. is its per-head abs-max needed."""
-    import torch
-
-    block = scaling in ("head", "head-wise") and (Skv + 63) // 64 <= 256 and (D != 128 or in_dtype == torch.bfloat16)
+    V is quantised per 64-key chunk -- no abs-max of V is read -- on every head dim and for both 16-bit input types (the D = 128 kernel
+    quantises Q itself and takes the chunk scales; the templated kernel at D = 64 / 256 takes them too) as long as a head has at most 256
+    chunks; only beyond that, and with token-wise scales, does V get one scale per head, i.e. is its per-head abs-max needed.
+    (`in_dtype`: no longer part of the rule -- until round 4 fp16 inputs at D = 128 kept the per-head V.)"""
+    block = scaling in ("head", "head-wise") and (Skv + 63) // 64 <= 256
     return not block

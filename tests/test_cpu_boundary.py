@@ -281,15 +281,16 @@ def test_compiled_region_carries_the_abs_max_reductions():
         args = dict(zip(names, op[0].args), **op[0].kwargs)
         n_amax = sum(1 for n in nodes if n.op == "call_method" and n.target == "amax")
         if inline:
-            # bf16, D = 128, 128 keys: V is block-scaled in the fused step, its abs-max is never read -- and not traced (ADVICE r4:
+            # 128 keys: V is block-scaled in the fused step (every head dim, bf16 and fp16), its abs-max is never read -- and not traced (ADVICE r4:
             # an op input cannot be eliminated as dead code, the graph would carry an extra read of V)
             assert n_amax == 2 and all(args.get(a) is not None for a in ("amax_q", "amax_k")) and args.get("amax_v") is None
             assert (args.get("ssq_q") is not None) == (precision == "auto") == (args.get("ssq_k") is not None)
         else:
             assert n_amax == 0 and all(args.get(a) is None for a in ("amax_q", "amax_k", "amax_v", "ssq_q", "ssq_k"))
-    # fp16 at D = 128 (V keeps one scale per head there): all three abs-max reductions are traced
+    # more than 256 chunks of keys per head (V keeps one scale per head there): all three abs-max reductions are traced
     torch._dynamo.reset()
+    kl, vl = (torch.randn(1, 2, 16448, 128, dtype=torch.bfloat16) for _ in range(2))
     with qa.config.patch({"attention.skip_supported_check": True, "attention.precision": "fast"}):
-        gm = torch._dynamo.export(f)(x.half(), k.half(), v.half()).graph_module
+        gm = torch._dynamo.export(lambda x_, k_, v_: qa.fp8_attn_func(x_ * 1.5, k_, v_))(x, kl, vl).graph_module
     assert sum(1 for n in gm.graph.nodes if n.op == "call_method" and n.target == "amax") == 3
     torch._dynamo.reset()

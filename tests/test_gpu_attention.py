@@ -78,6 +78,11 @@ CASES = [
     (1, 2, 2, 1024, 1024, 128, False, "e4m3", "token-wise", torch.bfloat16),
     (1, 2, 2, 1000, 1000, 128, True, "e4m3", "token-wise", torch.bfloat16),
     (1, 1, 1, 1, 1, 128, False, "e4m3", "head-wise", torch.bfloat16),           # single token
+    # fp16 inputs on the fused D = 128 path (round 5: in-kernel Q quantisation, block-scaled V and the 16-bit-V passes for both input types)
+    (1, 2, 2, 2304, 2304, 128, False, "e4m3", "head-wise", torch.float16),
+    (1, 2, 2, 2304, 2304, 128, True, "e4m3", "head-wise", torch.float16),
+    (1, 4, 2, 1500, 1500, 128, True, "e5m2", "head-wise", torch.float16),      # GQA, e5m2, ragged
+    (1, 2, 2, 700, 700, 128, False, "e4m3", "head-wise", torch.float16),       # fewer than 1024 keys: every block on the 16-bit V
     (1, 1, 1, 3, 70, 64, False, "e4m3", "head-wise", torch.bfloat16),
     (3, 5, 5, 300, 300, 128, True, "e4m3", "head-wise", torch.bfloat16),        # B*H not a multiple of 8
     (1, 2, 2, 1100, 1100, 64, True, "e4m3", "token-wise", torch.bfloat16),      # D = 64 / 256: every mode of the templated kernel
