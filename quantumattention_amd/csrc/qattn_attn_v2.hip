@@ -42,8 +42,17 @@
 
 #include "qattn_attn.h"
 #include "qattn_pv16.h"
+#include "qattn_pv16p.h"
 
 namespace qattn {
+
+// Where the workgroup's few words live (vote words, the hand-out mailbox, the head's V chunk scale words, the Q prefetch's dump slot: 2.1 KiB).
+// Behind the fp8 ring and the parked Q^T fragments -- except in the fused (Q16) kernels, whose pipelined 16-bit-V pass rings 120 KiB from
+// the start of LDS: there they sit in the last 4 KiB of the CU's 160 KiB (those kernels take all of it: one workgroup per CU either way).
+// The 16-bit-V rescue's parked Q^T fragments cover them too: rescue_pass and the kernel's block loop take out what they need first.
+constexpr int kLdsAll = 160 * 1024;
+template <int D, int NW, bool Q16>
+constexpr int v2_words_offset() { return (Q16 && NW == 8) ? kLdsAll - 4096 : 5 * 2 * 64 * D + NW * kQPerWave * D; }
 
 constexpr int kSyncEvery = 2;                   // waves synchronise every kSyncEvery 64-key iterations
 constexpr int kStagesV2 = 2 * kSyncEvery + 1;   // ring slots: G live + G being filled + the previous V stage
@@ -895,7 +904,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // only the writing lane ever reads them back, so no barrier is needed (the compiler orders the lane's own
     // ds_write -> ds_read with lgkmcnt).  NW words behind the Q area collect the waves' "a row of mine is peaked" votes.
     unsigned char* qbuf = smem + kStagesV2 * STAGE + wave * (KS << 11) + (hh << 10) + (ql << 4);
-    unsigned* vote = reinterpret_cast<unsigned*>(smem + kStagesV2 * STAGE + NW * kQPerWave * D);
+    unsigned* vote = reinterpret_cast<unsigned*>(smem + v2_words_offset<D, NW, Q16>());
     // fused step: the scale bytes of this head's V chunks (block-scaled V; 127 = 2^0 where V has one scale per head), kept in LDS
     // behind the votes for the PV products of every pass of this block; the sweep's first barrier publishes them
     unsigned* vx = vote + 16;
@@ -1004,7 +1013,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
             constexpr int RB = Q16 ? 2 * D : D;          // bytes per Q row
             constexpr int RPP = 1024 / RB;               // rows per 1 KiB piece
             const unsigned char* qsrc = Q16 ? p.q16 : p.q;
-            unsigned char* dump = smem + kStagesV2 * STAGE + NW * kQPerWave * D + 64 + 4 * kVxWords;
+            unsigned char* dump = smem + v2_words_offset<D, NW, Q16>() + 64 + 4 * kVxWords;
 #pragma unroll
             for (int j = 0; j < NPF; j++) {
                 const int r = min(qb2 * QWG + wave * kQPerWave + j * RPP + lane / (RB / 16), p.Sq - 1);
@@ -1058,7 +1067,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     // recompute its first row and store nothing)
     unsigned masks[NW];
     {
-        const volatile unsigned* vote = reinterpret_cast<const volatile unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D);
+        const volatile unsigned* vote = reinterpret_cast<const volatile unsigned*>(smem + v2_words_offset<D, NW, Q16>());
         v4i va, vb;
         lds_read_8words_raw(vote, va, vb);
 #pragma unroll
@@ -1147,8 +1156,15 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
     // MFMA time as the two-term pass, fewer vector instructions, and the rows that need the precision most no longer attend an fp8 V.
     auto pass16 = [&](volatile unsigned* mail_) {
         asm volatile("" : "+v"(tid));
-        pv16_block_pass<D, NW, QK_FMT, IN16, CAUSAL, false, true>(
-            p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); }, [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
+#ifndef QATTN_PV16_PIPELINED
+#define QATTN_PV16_PIPELINED 1   // (a build knob for tools/ab.py variants: 0 = the un-pipelined pass of round 4 everywhere)
+#endif
+        if constexpr (QATTN_PV16_PIPELINED != 0)
+            pv16p_block_pass<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); },
+                                                          [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
+        else
+            pv16_block_pass<D, NW, QK_FMT, IN16, CAUSAL, false, true>(
+                p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); }, [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
     };
     constexpr bool kPass16 = Q16 && NW == 8;   // (the fused step always carries the 16-bit V: qattn_api.hip quant_attention_impl)
     if constexpr (kPass16) {
@@ -1234,7 +1250,7 @@ template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BY
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // two words behind the waves' vote words carry a block number / queue item from thread 0 to the workgroup
-    volatile unsigned* bcast = reinterpret_cast<volatile unsigned*>(smem + kStagesV2 * 2 * 64 * D + NW * kQPerWave * D) + 8;
+    volatile unsigned* bcast = reinterpret_cast<volatile unsigned*>(smem + v2_words_offset<D, NW, Q16>()) + 8;
 #if defined(__HIP_DEVICE_COMPILE__)
     // the parameters are re-read from the kernel-argument segment every block (scalar loads): left to the compiler they
     // are hoisted out of the block loop, stay live across whole blocks and push the scalar file into spilling
@@ -1338,7 +1354,8 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
         p.sched = nullptr;
     }
     size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes + the Q prefetch's dump slot
-    if (Q16 && CHECK && NW == 8) lds = std::max(lds, (size_t)kRescue16VBytes + (size_t)NW * kQPerWave * D);   // the 16-bit-V rescue: eight V areas + the parked Q^T fragments = all 160 KiB (one workgroup per CU either way)
+    if (Q16 && NW == 8) lds = (size_t)kLdsAll;   // the fused kernels: the pipelined 16-bit-V pass's ring (5 x 24 KiB), the 16-bit-V rescue's V areas + parked Q^T fragments (all 160 KiB), the words at the end (v2_words_offset)
+    static_assert(kP16Stages * (64 * 128 + 64 * 2 * 128) <= kLdsAll - 4096 && kStagesV2 * 2 * 64 * 128 + 8 * kQPerWave * 128 <= kLdsAll - 4096, "the rings stay clear of the words");
 #ifdef QATTN_DEV
     if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
 #endif
