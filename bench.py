@@ -448,12 +448,27 @@ def run_rank(args):
             # where that kernel applies): step minus the in-step attention launches, against the same algorithmic bytes
             "quant_prepass_in_step_ms": line["ms_per_step"] - attn_ms,
             "quant_prepass_in_step_algorithmic_TBps": quant_alg_bytes / ((line["ms_per_step"] - attn_ms) * 1e-3) / 1e12 if line["ms_per_step"] > attn_ms else None,
+            # ... against what this box's HBM delivers to a plain copy (tensor.clone of 512 MiB: read + write), for the bytes the in-step
+            # pre-pass really moves at D = 128 head-wise: abs-max pass reads q and k (2 x 2 B per element), quantise pass reads k and v and
+            # writes k8 and v8 (2 x 3 B) -- 10 B per element of one tensor (the written bound)
+            "quant_prepass_in_step_traffic_bytes": 10 * B * H * S * D if D == 128 else None,
             "graph_replay_ms_per_step": graph_ms,
             "roofline": {"kernel": kernel_label(D, args.fp8, args.causal, D == 128),
                          "bound": "mfma", "achieved": achieved, "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP8_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source},
         })
         if world == 1 and not args.no_extras:
+            try:   # the HBM rate a plain copy reaches on this box, and the in-step pre-pass as a fraction of it
+                src = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+                cp_ms = event_time(lambda: src.clone(), 10)
+                copy_tbps = 2 * src.numel() / (cp_ms * 1e-3) / 1e12
+                del src
+                line["hbm_copy_TBps"] = copy_tbps
+                pre_ms, tb = line["quant_prepass_in_step_ms"], line["quant_prepass_in_step_traffic_bytes"]
+                if tb and pre_ms > 0:
+                    line["quant_prepass_in_step_frac_of_copy_rate"] = tb / (pre_ms * 1e-3) / 1e12 / copy_tbps
+            except Exception as exc:
+                print(f"[bench] copy-rate sample skipped: {exc}", file=sys.stderr)
             with qa.config.patch(cfg):
                 # sustained rate: >= 2 s of back-to-back steps, median of 20-step windows between HIP events (no host
                 # wait inside the run: the events are read after the last window)
