@@ -307,6 +307,9 @@ __device__ __forceinline__ unsigned lds_addr(const volatile void* p) {
 __device__ __forceinline__ void lds_write_word_raw(volatile unsigned* p, unsigned v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
 }
+__device__ __forceinline__ void lds_write_byte_raw(volatile void* p, unsigned v) {
+    asm volatile("ds_write_b8 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
 __device__ __forceinline__ unsigned lds_read_word_raw(const volatile unsigned* p) {
     unsigned v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr(p)) : "memory");
@@ -492,6 +495,13 @@ __device__ __forceinline__ void prep_scores(v16f& s0, v16f& s1, const AttnParams
 // About 0.3 of a 256-row block's sweep.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxRescueWaves = 2;   // (templated kernel) more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode
+// (fused step) flagged rows go to the 16-bit-V rescue (qattn_pv16.h rescue_rows16_at) when one of the block's flagged rows is SEVERELY
+// peaked, R = 1 / w_max < kPeakR16: the fp8 V's rounding then reaches the output with a weight above 1/8 (about 2^-7 for unit-variance
+// V).  Milder rows -- R between 8 and 24, all that flat data ever flags -- keep the two-term fp8 rescue, which takes two thirds of the time
+// (a rescue at the end of a launch is its tail: with every rescue on the 16-bit V the C2 step was 1.6 % slower, C3 2.3 %,
+// profiles/r05/ab_c{2,3}_all_rescues_16bit_vs_r4.log).
+constexpr float kPeakR16 = 8.0f;
+constexpr int kRescueSevere = 1 << 16;   // flag on attend_block's / run_block's row count
 constexpr int kMaxRescueRows = 96;   // (D = 128 kernel) more peaked rows than this in a 256-row block: redone; else gathered into <= 3 groups of 32 and recomputed
 
 __device__ __forceinline__ v8i gload_frag(const unsigned char* base) {

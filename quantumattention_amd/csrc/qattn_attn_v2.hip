@@ -832,7 +832,12 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
         draw_finish(p, mail, tid_draw, ticket);
         static_assert(NW <= 8, "eight vote words");
-        if (lane == 0) lds_write_word_raw(vote + wave, mine);
+        // (bytes 40 .. 47 behind the vote words and the mailbox: one per wave, "a flagged row of mine is severely peaked" -- kPeakR16)
+        const bool severe_mine = __any(peaked && l_tot * r_inv_pmax < kPeakR16) != 0;
+        if (lane == 0) {
+            lds_write_word_raw(vote + wave, mine);
+            lds_write_byte_raw(reinterpret_cast<volatile unsigned char*>(vote + 10) + wave, severe_mine ? 1u : 0u);
+        }
         lds_barrier();   // also: every wave is done with the K/V ring (the O rows just stored are nobody else's business)
         int nrows = 0;
         {
@@ -844,7 +849,10 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
         nrows = __builtin_amdgcn_readfirstlane(nrows);
         if (nrows == 0) return 0;
         if constexpr (!TOKEN && NW == 8) {
-            if (nrows <= p.max_rescue_rows) return nrows;   // rescue_pass gathers them from the vote words
+            if (nrows <= p.max_rescue_rows) {   // rescue_pass gathers them from the vote words
+                const unsigned sev = lds_read_word_raw(vote + 10) | lds_read_word_raw(vote + 11);
+                return nrows | (__builtin_amdgcn_readfirstlane((int)sev) != 0 ? kRescueSevere : 0);
+            }
         }
         return kPassRedo;   // many peaked rows: the whole block repeats in two-term mode (and rewrites every row)
     }
@@ -1043,7 +1051,9 @@ __device__ __forceinline__ int select_bit(unsigned m, int e) {
 }
 
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool Q16, int IN16 = QATTN_FMT_BF16>
-__device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, int nrows) {   // nrows: set bits of the block's vote words
+__device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* smem, int tid, int bid, int nrows_flag) {   // set bits of the block's vote words (| kRescueSevere)
+    const int nrows = nrows_flag & (kRescueSevere - 1);
+    const bool on16 = Q16 && (nrows_flag & kRescueSevere) != 0;   // (fused step) the 16-bit-V rescue, workgroup-uniform
     constexpr int CH = 64 * D;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1055,6 +1065,9 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
     const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
     const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
     const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
+    // (fused step, two-term rescue on the block-scaled fp8 V: the head's chunk scale words, left in LDS by the block's sweep -- nothing
+    // between the sweep and this pass touches the words' corner of LDS)
+    const unsigned* vx = reinterpret_cast<const unsigned*>(smem + v2_words_offset<D, NW, Q16>()) + 16;
     float c, scale_q16 = 1.0f;
     if (Q16) {
         const float inv_qmax = (float)(1.0 / (double)(QK_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
@@ -1073,7 +1086,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
 #pragma unroll
         for (int w = 0; w < NW; w++) masks[w] = (unsigned)(w < 4 ? va[w & 3] : vb[w & 3]);
     }
-    if (Q16) lds_barrier();   // (the 16-bit-V rescue's V areas cover the vote words: every wave has read them before any area is filled)
+    if (on16) lds_barrier();   // (the 16-bit-V rescue's V areas cover the vote words: every wave has read them before any area is filled)
     for (int g0 = 0; g0 < nrows; g0 += kQPerWave) {
         const bool have = g0 + ql < nrows;
         int e = have ? g0 + ql : g0, wsel = 0;
@@ -1113,23 +1126,27 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
         // parked in this lane's own slots of the workgroup's Q area (behind the ring), as the sweep does: held in registers for the
         // rescue loop they cost the causal fused instantiation two spilled registers
         // (fused step: behind the eight V areas of the 16-bit-V rescue, qattn_pv16.h rescue_rows16_at)
-        unsigned char* qslot = smem + (Q16 ? kRescue16VBytes : kStagesV2 * 2 * 64 * D) + wave * ((D / 64) << 11) + (hh << 10) + (ql << 4);
+        unsigned char* qslot = smem + (on16 ? kRescue16VBytes : kStagesV2 * 2 * 64 * D) + wave * ((D / 64) << 11) + (hh << 10) + (ql << 4);
 #pragma unroll
         for (int s_ = 0; s_ < D / 64; s_++) {
             const v8i f = qfrag(s_);
             *reinterpret_cast<v4i*>(qslot + (s_ << 11)) = v4i{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<v4i*>(qslot + (s_ << 11) + 512) = v4i{f[4], f[5], f[6], f[7]};
         }
+        bool done16 = false;
         if constexpr (Q16) {
-            // the fused step has the original 16-bit V at hand: the flagged rows -- rows whose weight sits on few keys, i.e. whose output carries
-            // V's rounding one to one -- get the reference kernel's own P.V numerics (16-bit P, 16-bit V), not two-term fp8 P on the fp8 V
-            const unsigned char* vg16 = p.v16 + kv_head * (long)p.Skv * (D * 2);
-            rescue_rows16_at<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, kg, vg16, row, have, row_lo, row_hi, wave, lane, bh, c,
-                                                                    [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); });
-        } else {
-            rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
-                                                                           [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, nullptr);
+            if (on16) {
+                // the fused step has the original 16-bit V at hand: where a flagged row's weight sits on very few keys (kPeakR16) -- its output
+                // carries V's rounding nearly one to one -- the group gets the reference kernel's own P.V numerics (16-bit P, 16-bit V)
+                const unsigned char* vg16 = p.v16 + kv_head * (long)p.Skv * (D * 2);
+                rescue_rows16_at<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, kg, vg16, row, have, row_lo, row_hi, wave, lane, bh, c,
+                                                              [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); });
+                done16 = true;
+            }
         }
+        if (!done16)
+            rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
+                                                                           [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, Q16 ? vx : nullptr);
     }
 }
 
@@ -1297,7 +1314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
         int next_drawn = -1;
         if constexpr (CHECK && !TOKEN && NW == 8 && Q16) {
             // (the 16-bit-V rescue's V areas cover the mailbox: the successor's number -- written before the block's vote barrier -- is taken out first)
-            if (resc != 0 && dynamic) next_drawn = __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
+            if ((resc & kRescueSevere) != 0 && dynamic) next_drawn = __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
         }
         if constexpr (CHECK && !TOKEN && NW == 8) {
             // a few peaked rows: on the spot, while the head's K / V are in this XCD's L2 (every wave is past the vote barrier, hence
@@ -1318,7 +1335,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
         if (dynamic) {
             // the successor was drawn in this block's prologue (draw_next_block)
             lds_barrier();   // also: every wave has left the ring and the Q slots before the next block fills them
-            next = (CHECK && !TOKEN && NW == 8 && Q16 && resc != 0) ? next_drawn : __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
+            next = (CHECK && !TOKEN && NW == 8 && Q16 && (resc & kRescueSevere) != 0) ? next_drawn : __builtin_amdgcn_readfirstlane((int)lds_read_word_raw(bcast + parity));
             parity ^= 1;
         } else if (!CAUSAL && bid + (int)gridDim.x < p.total_blocks) {
             next = bid + (int)gridDim.x;
