@@ -115,7 +115,7 @@ def test_16bit_kernel_vs_oracle(case):
 @pytest.mark.parametrize("D", [64, 128, 256])
 def test_16bit_fast_exponential_is_for_flat_rows_only(D):
     """config.attention.fast_exp16: 1.8 % rms error per weight averages out only over rows whose weight is spread over many
-    keys.  On q x 4 rows (a few keys carry each row) it must break 2^-6 while the exact default keeps 2^-7; the
+    keys (docs/DESIGN_history_rounds_1_to_4.md 4.4).  On q x 4 rows (a few keys carry each row) it must break 2^-6 while the exact default keeps 2^-7; the
     flag reaches the kernel through the op (qa.attn_func)."""
     torch.manual_seed(2)
     S = 2048

@@ -8,6 +8,8 @@ shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# the kernel sources the counters belong to (tools/summarize_profile.py stamps traffic.json with it; bench.py csrc_sha16 recomputes it)
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.csrc_sha16())" > $OUT/csrc_sha16.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 STEPS=${PROF_STEPS:-20}
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras $*"
