@@ -1,4 +1,4 @@
-"""-m gpu: a 200-configuration slice of the randomised sweeps in the regular suite (three rule defects were found by
+"""-m gpu: a 250-configuration slice of the randomised sweeps in the regular suite (three rule defects were found by
 widening these checks; they should not live as logs only).  The sweeps are the scripts under tools/ (one line per configuration, exit
 status 1 on any failure); each test runs a fixed-seed slice in a child process and keeps the transcript in the assertion message.
 
@@ -18,9 +18,9 @@ from tests.conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(script, n, seed):
+def _run(script, n, seed, *extra):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), str(n), str(seed)], capture_output=True, text=True, env=env,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), str(n), str(seed), *extra], capture_output=True, text=True, env=env,
                        timeout=1500)
     tail = "\n".join((p.stdout + p.stderr).splitlines()[-40:])
     assert p.returncode == 0, f"{script} {n} {seed} failed:\n{tail}"
@@ -30,6 +30,14 @@ def _run(script, n, seed):
 @pytest.mark.parametrize("seed", [401, 402, 403, 404])
 def test_parity_sweep_slice(seed):
     _run("fuzz_parity.py", 25, seed)
+
+
+@pytest.mark.parametrize("seed", [421, 422])
+def test_adversarial_parity_sweep_slice(seed):
+    """Round 5: two configurations of three carry a structure aimed at one rule of the precision machinery (tools/fuzz_parity.py::adversarial:
+    planted keys on both sides of the flag and 16-bit-rescue thresholds, a few equal keys, about 96 peaked rows per block, bimodal scores, the
+    dominant key in the last chunk, heavy-tailed V, zero rows, inputs near the top of fp16's range)."""
+    _run("fuzz_parity.py", 25, seed, "adv")
 
 
 @pytest.mark.parametrize("seed", [411, 412, 413, 414])
