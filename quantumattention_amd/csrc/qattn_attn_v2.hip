@@ -1176,12 +1176,14 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
 #ifndef QATTN_PV16_PIPELINED
 #define QATTN_PV16_PIPELINED 1   // (a build knob for tools/ab.py variants: 0 = the un-pipelined pass of round 4 everywhere)
 #endif
-        if constexpr (QATTN_PV16_PIPELINED != 0)
-            pv16p_block_pass<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); },
-                                                          [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
-        else
-            pv16_block_pass<D, NW, QK_FMT, IN16, CAUSAL, false, true>(
-                p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); }, [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
+        if constexpr (NW == 8) {   // (NW = 4: dev instantiations only, never the fused step)
+            if constexpr (QATTN_PV16_PIPELINED != 0)
+                pv16p_block_pass<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); },
+                                                              [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
+            else
+                pv16_block_pass<D, NW, QK_FMT, IN16, CAUSAL, false, true>(
+                    p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); }, [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
+        }
     };
     constexpr bool kPass16 = Q16 && NW == 8;   // (the fused step always carries the 16-bit V: qattn_api.hip quant_attention_impl)
     if constexpr (kPass16) {
@@ -1205,6 +1207,10 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
             var = sa * sb * p.var_mul;
             if (!(var >= kVarDeadband)) var = 1.0f;
         }
+        // (Round 5, measured and dropped: the sums REQUESTED here and looked at inside the one-term pass once its own small words had returned
+        // -- no round trip of their own in front of the block, 1.0 us of 64 in the dev work log -- with a block that then belongs on the other
+        // pass leaving the one-term pass at once: bit-identical, C2 -0.1 %, C3 -0.9 %, C5 -0.5 %, but q x 2 +1.4 % for the abandoned first
+        // requests; profiles/r05/ab_ssq_prefetch_vs_head_dropped.log.)
         const int nkeys = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;   // keys the block's first row attends
         // unit variance (or no estimate): the key-count rule; a head that IS wide: two-term when so many rows are expected to end peaked
         // that gathering and recomputing them would cost more than the two-term sweep
