@@ -122,6 +122,14 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     for (int g = kCausalHeadGroup; g > 1; g >>= 1)
         if (p.xcd_remap && ((a.B * a.Hq) >> 3) % g == 0 && (size_t)g * 2 * a.Skv * a.D <= kCausalGroupBytes) { p.causal_group = g; break; }
     // causal AUTO: the blocks right above the two-term line first (causal_order, qattn_attn.h)
+    // causal, XCD-aware hand-out: every head's blocks below the two-term line wait for the end of the XCD's list (map_block)
+    {
+        const int early = (kTwoTermKeys + kQPerWG - 2) / kQPerWG;
+#ifndef QATTN_TAIL_LO
+#define QATTN_TAIL_LO 1   // (a build knob for tools/ab.py variants: 0 = every group's own blocks, round 4's order)
+#endif
+        p.tail_lo = (QATTN_TAIL_LO != 0 && a.is_causal && p.xcd_remap && p.nqb >= 2 * early) ? early : 0;
+    }
     p.risky_lo = p.risky_hi = 0;
     if (a.is_causal && a.precision == QATTN_PRECISION_AUTO) {
         p.risky_lo = std::min(p.nqb, (kTwoTermKeys + kQPerWG - 2) / kQPerWG);   // blocks whose first row sees < kTwoTermKeys keys: qb < lo

@@ -103,6 +103,7 @@ struct AttnParams {
     int sched_zeroed;         // the hand-out counters were cleared by the kernel before this launch (fused step)
     int dyn_min_rounds;       // non-causal launches with at least this many blocks per workgroup use the dynamic hand-out too
     int risky_lo, risky_hi;   // causal, AUTO: query blocks [lo, hi) of a head go FIRST (map_block); lo = hi: plain longest-first
+    int tail_lo;              // causal, XCD-aware hand-out: the query blocks qb < tail_lo of ALL of an XCD's heads are handed out after everything else (map_block); 0: each group's own
     float sm_log2e;  // sm_scale * log2(e)
     int exact_exp;   // 1: v_exp_f32 + RNE fp8 conversion everywhere (no byte-exponential fast path)
     int precision;   // QATTN_PRECISION_*
@@ -437,6 +438,24 @@ __device__ inline void map_block(const AttnParams& p, int bid, int nqb, bool cau
     if (p.xcd_remap) {
         const int xcd = bid & 7, idx = bid >> 3, hpx = (p.B * p.Hq) >> 3;
         const int G = p.causal_group;
+        if (causal && p.tail_lo > 0) {
+            // Round 5: the lightest blocks of every head (qb < tail_lo: the rows that see fewer than kTwoTermKeys keys) are kept for the END of
+            // the XCD's list.  Handed out group by group, the last group's 75 us blocks were taken when only two dozen blocks were left and the
+            // launch ended on them with the other workgroups idle (35 us on average before the end of a C3 launch, 9 % of it: dev work log,
+            // profiles/r05/work_log_c3.log); a list that ends on 4 tail_lo hpx blocks of 6 .. 25 us fills that time.  They no longer find their
+            // head's K / V in L2 (they read at most a quarter of it).
+            const int nh = nqb - p.tail_lo, heavy = hpx * nh;
+            if (idx >= heavy) {   // heaviest first across the XCD's heads
+                const int i2 = idx - heavy;
+                qb = p.tail_lo - 1 - i2 / hpx;
+                head = xcd * hpx + i2 % hpx;
+                return;
+            }
+            const int per = G * nh, grp = idx / per, r = idx % per;
+            head = xcd * hpx + grp * G + r % G;
+            qb = causal_order(p, r / G, nqb);   // (slots < nqb - tail_lo: the risky blocks, then the long ones down to qb = tail_lo)
+            return;
+        }
         if (causal && G > 1) {
             const int per = G * nqb, grp = idx / per, r = idx % per;
             head = xcd * hpx + grp * G + r % G;

@@ -49,7 +49,7 @@ static int launch_d(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, in
 int launch_attn_pv16(const AttnParams& pin, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks) {
     AttnParams p = pin;
     p.total_blocks = 0;   // (here: "a whole-tensor launch", read by launch_one)
-    if (n_blocks > 0) { p.nqb = n_blocks < p.nqb ? n_blocks : p.nqb; p.risky_lo = p.risky_hi = 0; p.total_blocks = 1; }   // (the grid and map_block follow nqb)
+    if (n_blocks > 0) { p.nqb = n_blocks < p.nqb ? n_blocks : p.nqb; p.risky_lo = p.risky_hi = 0; p.tail_lo = 0; p.total_blocks = 1; }   // (the grid and map_block follow nqb)
     if (D == 64) return launch_d<64>(p, qk_fmt, v16_fmt, causal, scale_mode, st);
     if (D == 128) return launch_d<128>(p, qk_fmt, v16_fmt, causal, scale_mode, st);
     if (D == 256) return launch_d<256>(p, qk_fmt, v16_fmt, causal, scale_mode, st);

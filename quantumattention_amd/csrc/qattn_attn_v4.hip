@@ -460,6 +460,7 @@ static int launch_rescue_head(const AttnParams& p, int fmt, int causal, int row_
 template <int D>
 static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scale_mode, hipStream_t st) {
     AttnParams p = pin;
+    p.tail_lo = 0;
     p.risky_lo = p.risky_hi = 0;   // (plain longest-first: these launches cover sub-ranges of a head's blocks, and their rescues are launches of their own)
     // leading rows (a multiple of 256) that run two-term P from the start: all of them (QATTN_PRECISION_ACCURATE) or those
     // that see fewer than kTwoTermKeys keys
