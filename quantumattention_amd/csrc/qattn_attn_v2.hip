@@ -1210,7 +1210,8 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
         // (Round 5, measured and dropped: the sums REQUESTED here and looked at inside the one-term pass once its own small words had returned
         // -- no round trip of their own in front of the block, 1.0 us of 64 in the dev work log -- with a block that then belongs on the other
         // pass leaving the one-term pass at once: bit-identical, C2 -0.1 %, C3 -0.9 %, C5 -0.5 %, but q x 2 +1.4 % for the abandoned first
-        // requests; profiles/r05/ab_ssq_prefetch_vs_head_dropped.log.)
+        // requests; profiles/r05/ab_ssq_prefetch_vs_head_dropped.log.  With a per-workgroup hint word that takes the test up front again after a
+        // "wide" verdict the q x 2 cost goes, and so does most of the gain: ab_ssq_hint_and_light_last_vs_head_dropped.log.)
         const int nkeys = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;   // keys the block's first row attends
         // unit variance (or no estimate): the key-count rule; a head that IS wide: two-term when so many rows are expected to end peaked
         // that gathering and recomputing them would cost more than the two-term sweep
