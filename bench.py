@@ -599,9 +599,10 @@ def run_rank(args):
             except Exception as exc:
                 print(f"[bench] 16-bit-V mode sample skipped: {exc}", file=sys.stderr)
             # BASELINE configs 3 and 5: the same step with the causal mask, and the long-context e5m2 case
-            def extra(Bx, Hx, Sx, causal, fp8, n, dtype=torch.bfloat16):
+            def extra(Bx, Hx, Sx, causal, fp8, n, dtype=torch.bfloat16, token_wise=False):
                 qx, kx, vx = (torch.randn(Bx, Hx, Sx, D, dtype=dtype, device="cuda") for _ in range(3))
-                fn = lambda: qa.fp8_attn_func(qx, kx, vx, is_causal=causal)
+                step = qa.fp8_token_wise_attn_func if token_wise else qa.fp8_attn_func
+                fn = lambda: step(qx, kx, vx, is_causal=causal)
                 with qa.config.patch({"attention.fp8_format": fp8, "attention.precision": args.precision}):
                     ms = event_time(fn, n)
                     ams = attn_in_step(fn, n)
@@ -614,6 +615,10 @@ def run_rank(args):
                 line["c2_fp16"] = extra(4, 32, 4096, False, "e4m3", 20, dtype=torch.float16)
                 line["c3_fp16"] = extra(4, 32, 4096, True, "e4m3", 20, dtype=torch.float16)
                 line["c5_causal_e5m2_B4_H40_S16384"] = extra(4, 40, 16384, True, "e5m2", 5)
+                # the reference's second scaling mode (fp8_token_wise_attn_func, quantum_attn_interface.py:179-202) at the C2 / C3 shape: per-row
+                # scales of q and k, on the templated kernel (csrc/qattn_attn_v4.hip)
+                line["c2_token_wise"] = extra(4, 32, 4096, False, "e4m3", 20, token_wise=True)
+                line["c3_token_wise"] = extra(4, 32, 4096, True, "e4m3", 20, token_wise=True)
                 # the reference's own benchmark grid (tests/test_interface.py:95-102,141-156): B16 H16 S8192, D in {64,128,256}
                 ref_grid = {}
                 for Dx, dtx in [(d_, t_) for t_ in (torch.bfloat16, torch.float16) for d_ in (64, 128, 256)]:

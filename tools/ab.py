@@ -23,6 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 vp, i, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 PREC = {"auto": 0, "fast": 1, "accurate": 2}
+SCALE_MODE = 0   # --token: 1 (per-row scales of q and k)
 FMT = {"e4m3": 0, "e5m2": 1}
 
 
@@ -50,7 +51,7 @@ class Variant:
         u8 = lambda n: torch.empty((max(int(n), 16),), dtype=torch.uint8, device=dev)
         self.q8 = u8(B * H * S * D)
         self.kf = u8(L.qattn_fp8_tensor_bytes(1, B, H, S, D)); self.vf = u8(L.qattn_fp8_tensor_bytes(2, B, H, S, D))
-        self.sq, self.sk, self.sv = (torch.empty((B, H), dtype=torch.float32, device=dev) for _ in range(3))
+        self.sq, self.sk, self.sv = (torch.empty((B, H, S) if (SCALE_MODE and n < 2) else (B, H), dtype=torch.float32, device=dev) for n in range(3))
         self.out = torch.empty_like(q)
         self.ws_q = u8(L.qattn_quant_qkv_workspace_bytes(B, H, H)); self.ws_a = u8(L.qattn_attention_workspace_bytes(B, H, S))
         self.ws_f = u8(L.qattn_fp8_quant_attention_workspace_bytes(B, H, H, S))
@@ -68,19 +69,19 @@ class Variant:
         B, H, S, D = self.dims
         self._chk(self.L.qattn_quant_qkv_fp8(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(), 2, self.q8.data_ptr(), self.kf.data_ptr(),
                                              self.vf.data_ptr(), self.sq.data_ptr(), self.sk.data_ptr(), self.sv.data_ptr(), B, H, H, S, S, D,
-                                             self.fp8, 0, 0, self.ws_q.data_ptr(), self.ws_q.numel(), self.st), "quant_qkv")
+                                             self.fp8, SCALE_MODE, 0, self.ws_q.data_ptr(), self.ws_q.numel(), self.st), "quant_qkv")
 
     def attn(self, prec):
         B, H, S, D = self.dims
         self._chk(self.L.qattn_fp8_attention_forward(self.q82.data_ptr(), self.kf2.data_ptr(), self.vf2.data_ptr(), self.out.data_ptr(), None,
                                                      self.sq2.data_ptr(), self.sk2.data_ptr(), self.sv2.data_ptr(), B, H, H, S, S, D, self.fp8, self.fp8, 2,
-                                                     0, self.causal, 0.0, prec, 0, self.ws_a.data_ptr(), self.ws_a.numel(), self.st), "attention")
+                                                     SCALE_MODE, self.causal, 0.0, prec, 0, self.ws_a.data_ptr(), self.ws_a.numel(), self.st), "attention")
 
     def fused(self, prec):
         B, H, S, D = self.dims
         self._chk(self.L.qattn_fp8_quant_attention_forward(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(), 2, self.out.data_ptr(),
                                                            self.q8.data_ptr(), self.kf.data_ptr(), self.vf.data_ptr(), self.sq.data_ptr(), self.sk.data_ptr(),
-                                                           self.sv.data_ptr(), B, H, H, S, S, D, self.fp8, 0, 0, self.causal, 0.0, prec,
+                                                           self.sv.data_ptr(), B, H, H, S, S, D, self.fp8, SCALE_MODE, 0, self.causal, 0.0, prec,
                                                            self.ws_f.data_ptr(), self.ws_f.numel(), self.st), "fused step")
 
 
@@ -96,7 +97,10 @@ def main():
     ap.add_argument("--fp8", default="e4m3")
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies q (score spread)")
     ap.add_argument("--settle", type=float, default=0.5)
+    ap.add_argument("--token", action="store_true", help="token-wise scales of q and k (QATTN_SCALE_TOKEN)")
     a = ap.parse_args()
+    global SCALE_MODE
+    SCALE_MODE = 1 if a.token else 0
     libs, envs = [], {}
     for x in a.libs:
         n, rest = x.split("=", 1)
