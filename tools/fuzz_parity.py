@@ -147,6 +147,11 @@ for case in range(N):
         np.array_equal(unpack_frag(bits8(kf), _native.LAYOUT_KFRAG, B, Hkv, Skv, D)[:, :, :Skv], k8) and np.array_equal(skg.cpu().numpy(), sk)
     # the bound is absolute for N(0,1)-like V (errors are ~ eps w |v - O|): it scales with V's spread, and with |O| for the output rounding
     tol = TOL * max(1.0, float(np.abs(ref).max()) / 2, float(v.float().std()))
+    if structure == "heavy_tailed_v":
+        # the bound is 0.074 w |v - O| with w < 1 / 24 for the keys a one-term row may keep: 2^-6 for |v - O| up to
+        # ~ 4.5, what N(0, 1) values reach -- x^3 values reach 15 .. 30 standard deviations, and the bound follows the largest |v|, not the
+        # spread (found by this generator, seed 82 case 116: 0.089 against 2^-6 x 3.85 on a row with a weight of 1 / 50 on a |v| of 60)
+        tol = max(tol, TOL * float(v.float().abs().max()) / 4.5)
     mx_f, _ = err_stats(fused, ref)
     mx_s, _ = err_stats(sep, ref_sep)
     finite = bool(np.isfinite(fused).all() and np.isfinite(sep).all())
