@@ -386,43 +386,60 @@ static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode,
 
 // Rescue launch: one 8-wave workgroup per 256-row block; the flagged 32-row groups of a block with at most kMaxRescueWaves of
 // them are recomputed by rescue_rows (qattn_attn.h), the Q^T fragments fetched from the row-major q8 tensor.
+// 256-row blocks a workgroup of the rescue launch looks at (64 flag words: one per lane).  Non-causal calls only: there the launch is a few
+// dozen rescues among thousands of empty workgroups; a causal call flags a quarter of its blocks (the rows that see 1 .. 2 k keys), and
+// several rescues in a row per workgroup made its launch 20 .. 70 % longer (profiles/r05/ab_v4_rescue_scan_*).
+template <bool CAUSAL> constexpr int rescue_scan() { return CAUSAL ? 1 : 8; }
 template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
 __global__ __launch_bounds__(512, 2) void rescue_groups_kernel(const AttnParams p, const int blk_lo, const int blk_n) {
     constexpr int CH = 64 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ql = lane & 31, hh = lane >> 5;
-    int head, blk;
-    map_block(p, blockIdx.x, blk_n, false, head, blk);
-    blk += blk_lo;
-    const int b = head / p.Hq, h = head % p.Hq;
-    const long bh = (long)b * p.Hq + h;
-    const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+    // One workgroup looks at rescue_scan() 256-row blocks (of the (b, h, block) order: 8 flag words each, one word per lane, ONE
+    // memory round trip) and recomputes what it finds.  One workgroup per block -- rounds 3 and 4 -- made the launch as long as its
+    // thousands of empty workgroups' round trips: 65 us at B16 H16 S8192 with a few dozen groups to recompute (dev kernel trace,
+    // profiles/r05/kstats_d64_reference_shape.txt).
     const int ng = (p.Sq + 31) >> 5;
-    unsigned flagged = 0;
-    for (int g = 0; g < 8; g++)
-        if (blk * 8 + g < ng && p.flags[bh * ng + blk * 8 + g] != 0u) flagged |= 1u << g;
-    flagged = __builtin_amdgcn_readfirstlane(flagged);
-    if (flagged == 0u || __builtin_popcount(flagged) > kMaxRescueWaves) return;   // nothing to do / redone by the two-term launch
-    const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
-    const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
-    const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
-    for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
-        const int r0 = blk * 256 + __builtin_ctz(rest) * kQPerWave, row = r0 + ql;
-        const bool qvalid = row < p.Sq;
-        float c;
-        if (TOKEN) c = p.sm_log2e * (qvalid ? p.sq[bh * p.Sq + row] : 1.0f);
-        else c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
-        const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? row : 0)) * D) + hh * 32;
-        auto qfrag = [&](int s_) {
-            v4i lo = *reinterpret_cast<const v4i*>(qp + s_ * 64);
-            v4i hi = *reinterpret_cast<const v4i*>(qp + s_ * 64 + 16);
-            if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
-            return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        };
-        // (block-scaled V: the chunk scale bytes straight from global memory, one word per chunk)
-        rescue_rows<D, 8, QK_FMT, V_FMT, CAUSAL, TOKEN, false, !TOKEN>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, skt, qfrag,
-                                                                       (!TOKEN && p.vexp) ? p.vexp + kv_head * p.vexp_stride : nullptr);
+    const int nb = p.B * p.Hq * blk_n;
+    // (blocks blockIdx.x, + gridDim.x, ...: the flagged blocks of a causal call are the same few of every head, side by side in that order)
+    const int n0 = (int)blockIdx.x + (lane >> 3) * (int)gridDim.x, g_l = lane & 7;
+    unsigned long long found;
+    {
+        const int bh_l = n0 / blk_n, blk_l = blk_lo + n0 % blk_n;
+        const bool valid = (lane >> 3) < rescue_scan<CAUSAL>() && n0 < nb && blk_l * 8 + g_l < ng;
+        const unsigned f = valid ? p.flags[(long)bh_l * ng + blk_l * 8 + g_l] : 0u;
+        found = __ballot(f != 0u);   // byte i: the flagged groups of block blockIdx.x + i gridDim.x (the same in every wave)
+    }
+    for (int i = 0; i < rescue_scan<CAUSAL>(); i++) {
+        const unsigned flagged = __builtin_amdgcn_readfirstlane((unsigned)(found >> (8 * i)) & 0xffu);
+        if (flagged == 0u || __builtin_popcount(flagged) > kMaxRescueWaves) continue;   // nothing to do / redone by the two-term launch
+        const int n = (int)blockIdx.x + i * (int)gridDim.x;
+        const long bh = n / blk_n;
+        const int blk = blk_lo + n % blk_n;
+        const int b = (int)(bh / p.Hq), h = (int)(bh % p.Hq);
+        const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+        const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
+        const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
+        const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
+        for (unsigned rest = flagged; rest != 0u; rest &= rest - 1u) {
+            const int r0 = blk * 256 + __builtin_ctz(rest) * kQPerWave, row = r0 + ql;
+            const bool qvalid = row < p.Sq;
+            float c;
+            if (TOKEN) c = p.sm_log2e * (qvalid ? p.sq[bh * p.Sq + row] : 1.0f);
+            else c = p.sm_log2e * p.sq[bh] * p.sk[kv_head];
+            const unsigned char* qp = p.q + ((bh * p.Sq + (qvalid ? row : 0)) * D) + hh * 32;
+            auto qfrag = [&](int s_) {
+                v4i lo = *reinterpret_cast<const v4i*>(qp + s_ * 64);
+                v4i hi = *reinterpret_cast<const v4i*>(qp + s_ * 64 + 16);
+                if (!qvalid) { lo = v4i{0, 0, 0, 0}; hi = v4i{0, 0, 0, 0}; }
+                return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+            // (block-scaled V: the chunk scale bytes straight from global memory, one word per chunk)
+            rescue_rows<D, 8, QK_FMT, V_FMT, CAUSAL, TOKEN, false, !TOKEN>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, skt, qfrag,
+                                                                           (!TOKEN && p.vexp) ? p.vexp + kv_head * p.vexp_stride : nullptr);
+            __syncthreads();   // (the next group's K prefetch areas alias this one's merge slots)
+        }
     }
 }
 
@@ -433,7 +450,7 @@ static int launch_rescue_one(const AttnParams& p, int row_lo, hipStream_t st) {
     const size_t lds = 4 * (size_t)rescue_slot_bytes<D>();
     auto kern = rescue_groups_kernel<D, FMT, FMT, CAUSAL, TOKEN>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(p.B * p.Hq * blk_n), dim3(512), lds, st, p, blk_lo, blk_n);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.B * p.Hq * blk_n, rescue_scan<CAUSAL>())), dim3(512), lds, st, p, blk_lo, blk_n);
     return QATTN_OK;
 }
 

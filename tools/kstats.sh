@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel average durations of the fused step under rocprofv3 (run on the GPU box):  tools/kstats.sh <tag> [env assignments for dbg_trace_step.py]
+# per-kernel average durations of the fused step under rocprofv3 (run on the GPU box):  tools/kstats.sh <tag> [env assignments for trace_step.py]
 # -> gpurun_out/kstats_<tag>.txt
 set -u
 TAG=$1; shift
@@ -9,7 +9,7 @@ mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
 case "${QLIB:-}" in ""|/*) ;; *) export QLIB=$ROOT/$QLIB;; esac
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tools/dbg_trace_step.py > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tools/trace_step.py > $OUT/run.log 2>&1
 F=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python3 - "$F" > $ROOT/gpurun_out/kstats_$TAG.txt <<'PY'
 import csv, sys
