@@ -389,7 +389,8 @@ static int launch_v4_d(const AttnParams& p, int fmt, int causal, int scale_mode,
 // 256-row blocks a workgroup of the rescue launch looks at (64 flag words: one per lane).  Non-causal calls only: there the launch is a few
 // dozen rescues among thousands of empty workgroups; a causal call flags a quarter of its blocks (the rows that see 1 .. 2 k keys), and
 // several rescues in a row per workgroup made its launch 20 .. 70 % longer (profiles/r05/ab_v4_rescue_scan_*).
-template <bool CAUSAL> constexpr int rescue_scan() { return CAUSAL ? 1 : 8; }
+// (D = 256: one block, too -- the loop around rescue_rows costs that instantiation three spilled registers)
+template <bool CAUSAL, int D> constexpr int rescue_scan() { return (CAUSAL || D == 256) ? 1 : 8; }
 template <int D, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN>
 __global__ __launch_bounds__(512, 2) void rescue_groups_kernel(const AttnParams p, const int blk_lo, const int blk_n) {
     constexpr int CH = 64 * D;
@@ -407,18 +408,20 @@ __global__ __launch_bounds__(512, 2) void rescue_groups_kernel(const AttnParams 
     unsigned long long found;
     {
         const int bh_l = n0 / blk_n, blk_l = blk_lo + n0 % blk_n;
-        const bool valid = (lane >> 3) < rescue_scan<CAUSAL>() && n0 < nb && blk_l * 8 + g_l < ng;
+        const bool valid = (lane >> 3) < rescue_scan<CAUSAL, D>() && n0 < nb && blk_l * 8 + g_l < ng;
         const unsigned f = valid ? p.flags[(long)bh_l * ng + blk_l * 8 + g_l] : 0u;
         found = __ballot(f != 0u);   // byte i: the flagged groups of block blockIdx.x + i gridDim.x (the same in every wave)
     }
-    for (int i = 0; i < rescue_scan<CAUSAL>(); i++) {
+    for (int i = 0; i < rescue_scan<CAUSAL, D>(); i++) {
         const unsigned flagged = __builtin_amdgcn_readfirstlane((unsigned)(found >> (8 * i)) & 0xffu);
         if (flagged == 0u || __builtin_popcount(flagged) > kMaxRescueWaves) continue;   // nothing to do / redone by the two-term launch
-        const int n = (int)blockIdx.x + i * (int)gridDim.x;
-        const long bh = n / blk_n;
-        const int blk = blk_lo + n % blk_n;
-        const int b = (int)(bh / p.Hq), h = (int)(bh % p.Hq);
-        const long kv_head = (long)b * p.Hkv + h / (p.Hq / p.Hkv);
+        // (workgroup-uniform values, kept in scalar registers: rescue_rows needs every vector register it can get)
+        const int n = __builtin_amdgcn_readfirstlane((int)blockIdx.x + i * (int)gridDim.x);
+        const int bh_i = __builtin_amdgcn_readfirstlane(n / blk_n);
+        const long bh = bh_i;
+        const int blk = __builtin_amdgcn_readfirstlane(blk_lo + n % blk_n);
+        const int b = bh_i / p.Hq, h = bh_i % p.Hq;
+        const long kv_head = __builtin_amdgcn_readfirstlane(b * p.Hkv + h / (p.Hq / p.Hkv));
         const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
         const unsigned char* vg = p.v + kv_head * (long)p.nchunks * CH;
         const float* skt = TOKEN ? p.sk + kv_head * p.Skv : nullptr;
@@ -450,7 +453,7 @@ static int launch_rescue_one(const AttnParams& p, int row_lo, hipStream_t st) {
     const size_t lds = 4 * (size_t)rescue_slot_bytes<D>();
     auto kern = rescue_groups_kernel<D, FMT, FMT, CAUSAL, TOKEN>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.B * p.Hq * blk_n, rescue_scan<CAUSAL>())), dim3(512), lds, st, p, blk_lo, blk_n);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.B * p.Hq * blk_n, rescue_scan<CAUSAL, D>())), dim3(512), lds, st, p, blk_lo, blk_n);
     return QATTN_OK;
 }
 
