@@ -77,11 +77,14 @@ extern "C" {
  * (src/quantum_attn/tk/attention.py:72,286,318); here P is e4m3, and ONE e4m3 term (3 mantissa bits) is accurate enough
  * only for rows whose weight is spread over many keys:
  *   AUTO     (default) one-term P, checked per row: a 256-row query block in which some row's largest softmax weight
- *            exceeds 1/24 (R = l / p_max < 24) has those rows' 32-row groups (or, if many, the whole block) recomputed with
- *            two-term (hi + lo) P.
+ *            exceeds 1/24 (R = l / p_max < 24; or whose effective key count is below 192) has those rows (or, if many, the
+ *            whole block) recomputed with more precision.
  *   FAST     one-term P wherever a row sees >= 1024 keys (what other fp8 attention kernels do); no check.
- *   ACCURATE two-term P everywhere (~bf16-P accuracy, 1.5x the matrix work).
- * In every mode query blocks that see fewer than 1024 keys (short sequences, early causal rows) use two-term P. */
+ *   ACCURATE the precise pass everywhere (~bf16-P accuracy, 1.5x the matrix work).
+ * "More precision" is two-term (hi + lo) e4m3 P on the fp8 V -- or, in the fused entry (qattn_fp8_quant_attention_forward, which
+ * has the caller's 16-bit V at hand) at D = 128 with head-wise scales, the reference kernel's own numerics: 16-bit P on the original
+ * 16-bit V (whole blocks; rescued rows with a weight above 1/8).  In every mode query blocks that see fewer than 1024 keys
+ * (short sequences, early causal rows) take the precise pass. */
 #define QATTN_PRECISION_AUTO 0
 #define QATTN_PRECISION_FAST 1
 #define QATTN_PRECISION_ACCURATE 2
@@ -185,14 +188,14 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
  * and one write of Q.  For every head dim, 16-bit input format and scale mode the query blocks (256 rows) whose first row sees fewer
  * than 1024 keys -- early causal rows, every row of a short sequence -- attend the ORIGINAL 16-bit V with 16-bit P (the reference's
- * numerics, as v_fmt = 16-bit above) instead of the quantised V: inside the fused kernel for bf16 head-wise inputs, by a launch of
+ * numerics, as v_fmt = 16-bit above) instead of the quantised V: inside the fused kernel for head-wise D = 128 inputs (bf16 and fp16), by a launch of
  * their own otherwise; on those rows the step's results are NOT those of the separate calls (which only have the fp8 V).  There, and with head-wise scales at D = 64 / 256 (both for Skv <= 16384), V is also quantised
  * differently from qattn_quant_qkv_fp8: one power-of-two scale per 64-key chunk, found inside the quantise pass (no abs-max pass over V) and applied by the kernel's PV products as
  * the MFMA's E8M0 block scale; v8 then holds those payloads, scale_v is written as 1.0 and the chunk scales live in the
  * workspace (oracle restatement: oracle.quantize_v_block).  Everywhere else results are bit-identical to the separate
  * calls, with one more documented exception: under
  * QATTN_PRECISION_AUTO (head-wise, D = 128) the pre-pass also hands the attention kernel every head's sum of squares, and a
- * head whose predicted score variance is >= 1.5 starts in two-term mode (what QATTN_PRECISION_ACCURATE computes for it) instead
+ * head whose predicted score variance is >= 1.5 starts on the precise pass (what QATTN_PRECISION_ACCURATE computes for it) instead
  * of being swept once with one-term P first; heads below that -- N(0,1)-like data -- take the same decisions as the separate calls.
  */
 size_t qattn_fp8_quant_attention_workspace_bytes(int B, int Hq, int Hkv, int Sq);
@@ -211,7 +214,7 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
  *   amax_q / amax_k / amax_v  NULL, or fp32 [B,Hq] / [B,Hkv] / [B,Hkv]: max |x| over each head of the 16-bit tensor, exactly (the
  *                             fp32 value of the largest 16-bit magnitude).  A tensor with a supplied abs-max takes no part in the
  *                             abs-max launch; with all of them supplied (amax_v is not needed where V is block-scaled: head-wise
- *                             scales, Skv <= 16384, D = 64 / 256 or D = 128 from bf16 inputs) the launch is skipped -- at B4 H32 S4096 D128 that is 0.05 of 0.64 ms.  The
+ *                             scales, Skv <= 16384, every head dim, bf16 and fp16 inputs) the launch is skipped -- at B4 H32 S4096 D128 that is 0.05 of 0.64 ms.  The
  *                             results are bit-identical to qattn_fp8_quant_attention_forward's -- under QATTN_PRECISION_AUTO when
  *                             ssq_q / ssq_k come along (below), except for a head whose estimated score variance sits exactly on
  *                             the dead-band edge (1.5): the caller's fp32 sums differ from the pass's partial sums in the last

@@ -24,10 +24,11 @@ class attention:
     quant_numerics = os.getenv("QUANTUM_ATTN_QUANT_NUMERICS", "compiled")
 
     # how the probabilities P enter the second fp8 GEMM:
-    #   "auto"     one-term e4m3 P where the softmax row is spread over enough keys; every 256-row query block in which a
-    #              row turns out to be peaked (few keys carry the weight) is recomputed with two-term (hi + lo) P
+    #   "auto"     one-term e4m3 P where the softmax row is spread over enough keys; the rows of a 256-row query block that turn
+    #              out to be peaked (few keys carry the weight) are recomputed with more precision: two-term (hi + lo) fp8 P, or --
+    #              fused step, head_dim 128, head-wise -- 16-bit P on the original 16-bit V (the reference kernel's numerics)
     #   "fast"     one-term P everywhere (what other fp8 attention kernels do); error grows with the sharpness of the rows
-    #   "accurate" two-term P everywhere (about bf16-P accuracy, ~1.5x the matrix work)
+    #   "accurate" the precise pass everywhere (about bf16-P accuracy, ~1.5x the matrix work)
     precision = os.getenv("QUANTUM_ATTN_PRECISION", "auto")
 
     # the P.V product of `fp8_attention_forward` on pre-quantised query / key (the reference's op contract: value arrives in 16 bit):
