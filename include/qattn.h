@@ -184,7 +184,7 @@ int qattn_fp8_attention_forward(const void* q8, const void* k8, const void* v8, 
  * The whole step of `_fp8_attention_wrapper` for 16-bit inputs (nn.py:394-430: quantise q and k, then the fp8 op) in one
  * call: pre-pass (qattn_quant_qkv_fp8 semantics) + attention (qattn_fp8_attention_forward semantics, no LSE) on `stream`.
  * q8 / k8 / v8 / scale_* are caller-provided outputs+scratch with the sizes qattn_quant_qkv_fp8 documents; `workspace` needs
- * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16,
+ * qattn_fp8_quant_attention_workspace_bytes().  Where the attention kernel can quantise its own Q rows (D = 128, bf16 or fp16,
  * head-wise) the pre-pass skips Q's payload -- q8 is then left untouched, scale_q is still written -- which saves one read
  * and one write of Q.  For every head dim, 16-bit input format and scale mode the query blocks (256 rows) whose first row sees fewer
  * than 1024 keys -- early causal rows, every row of a short sequence -- attend the ORIGINAL 16-bit V with 16-bit P (the reference's
