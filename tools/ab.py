@@ -7,7 +7,8 @@ its own operands, and each (library, precision, path) variant is timed with HIP 
                      [--rounds 7] [--calls 20] [--fp8 e4m3] [--scale 1.0] [--settle 0.5]
   paths: fused = qattn_fp8_quant_attention_forward (the bench step), attn = qattn_fp8_attention_forward on pre-quantised
          operands, quant = qattn_quant_qkv_fp8.
-  default libraries: new=quantumattention_amd/libqattn_hip.so r2=tools/ab_libs/libqattn_r2.so (if present)
+  default libraries: new=quantumattention_amd/libqattn_hip.so r4=tools/ab_libs/libqattn_r4.so (if present)
+  --token: token-wise scales of q and k
   name=path@VAR=VAL[@VAR2=VAL2]: environment set around that variant's calls (dev library switches that are read per call)
 Prints median / min ms per variant and the ratio to the first library's variant of the same (precision, path).
 """
@@ -109,8 +110,8 @@ def main():
         envs[n] = dict(e.split("=", 1) for e in parts[1:])
     if not libs:
         libs = [["new", os.path.join(ROOT, "quantumattention_amd", "libqattn_hip.so")]]
-        if os.path.exists(os.path.join(ROOT, "tools", "bin", "libqattn_r2.so")):
-            libs.append(["r2", os.path.join(ROOT, "tools", "bin", "libqattn_r2.so")])
+        if os.path.exists(os.path.join(ROOT, "tools", "ab_libs", "libqattn_r4.so")):
+            libs.append(["r4", os.path.join(ROOT, "tools", "ab_libs", "libqattn_r4.so")])
     B, H, S, D = (int(x) for x in a.shape.split(","))
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
