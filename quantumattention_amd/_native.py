@@ -14,9 +14,10 @@ FMT_E4M3, FMT_E5M2, FMT_BF16, FMT_FP16 = 0, 1, 2, 3
 SCALE_HEAD, SCALE_TOKEN = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_KFRAG, LAYOUT_VFRAG, LAYOUT_K16FRAG, LAYOUT_V16FRAG = 0, 1, 2, 3, 4
 NUMERICS = {"compiled": 0, "eager": 1}
-ABI_VERSION = 6
+ABI_VERSION = 7
 PRECISION = {"auto": 0, "fast": 1, "accurate": 2}
 LSE_NATURAL, LSE_REFERENCE = 0, 1
+PATH_ONE_TERM, PATH_TWO_TERM, PATH_V16 = 0, 1, 2   # QATTN_PATH_*: the fused entry's per-row debug output
 
 _FMT_OF_DTYPE = {
     torch.float8_e4m3fn: FMT_E4M3,
@@ -34,7 +35,22 @@ EXPORTS = (
     "qattn_attention_workspace_bytes", "qattn_lse_row_stride", "qattn_fp8_quant_attention_workspace_bytes",
     "qattn_profile_attention", "qattn_last_attention_ms", "qattn_vblock_exponent", "qattn_fp8_quant_attention_forward_ex",
     "qattn_attention_stamp_bytes", "qattn_fp8_quant_attention_forward_stamped", "qattn_mfma_probe_bytes", "qattn_mfma_probe",
+    "qattn_fp8_attention_rowmajor_workspace_bytes", "qattn_fp8_attention_forward_rowmajor", "qattn_describe_path",
 )
+
+
+class PathDesc(ctypes.Structure):
+    """qattn_path_desc (include/qattn.h): what an entry runs for given arguments."""
+    _fields_ = [(n, ctypes.c_int) for n in ("kernel", "q_quant", "v_format", "sweep_p", "precise", "early", "start_mode", "lse")]
+
+
+ENTRY = {"separate": 0, "separate16": 1, "fused": 2}
+# names of the enum values of qattn_path_desc's fields, in the order of their codes (the vocabulary of the header's path table)
+PATH_DESC_NAMES = {
+    "kernel": ("v2", "v4", "pv16"), "q_quant": ("caller", "prepass", "kernel"), "v_format": ("head", "block", "16bit"),
+    "sweep_p": ("byte", "exact", "p16"), "precise": ("two-term", "v16", "none"), "early": ("two-term", "v16-inline", "v16-launch", "none"),
+    "start_mode": ("keys", "moments", "none"), "lse": ("exact", "quantised"),
+}
 
 _lib = None
 
@@ -96,7 +112,7 @@ def lib() -> ctypes.CDLL:
     L.qattn_fp8_quant_attention_forward.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp]
     L.qattn_fp8_quant_attention_forward_ex.restype = i
     L.qattn_fp8_quant_attention_forward_ex.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                                       i, i, i, i, i, i, i, i, i, i, f, i, vp, sz, vp]
+                                                       i, i, i, i, i, i, i, i, i, i, f, i, vp, i, vp, vp, sz, vp]
     L.qattn_attention_stamp_bytes.restype = sz
     L.qattn_attention_stamp_bytes.argtypes = [i, i, i]
     L.qattn_fp8_quant_attention_forward_stamped.restype = i
@@ -105,6 +121,12 @@ def lib() -> ctypes.CDLL:
     L.qattn_mfma_probe_bytes.argtypes = []
     L.qattn_mfma_probe.restype = i
     L.qattn_mfma_probe.argtypes = [vp, sz, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), vp]
+    L.qattn_fp8_attention_rowmajor_workspace_bytes.restype = sz
+    L.qattn_fp8_attention_rowmajor_workspace_bytes.argtypes = [i, i, i, i, i, i]
+    L.qattn_fp8_attention_forward_rowmajor.restype = i
+    L.qattn_fp8_attention_forward_rowmajor.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, i, i, vp, sz, vp]
+    L.qattn_describe_path.restype = i
+    L.qattn_describe_path.argtypes = [i, i, i, i, i, i, ctypes.POINTER(PathDesc)]
     if L.qattn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libqattn_hip.so ABI {L.qattn_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = L
@@ -288,6 +310,45 @@ def fp8_attention_forward(q8: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.
     return out
 
 
+def describe_path(entry: str, D: int, in_dtype=torch.bfloat16, scaling: str = "head-wise", Skv: int = 4096, want_lse: bool = False) -> dict:
+    """qattn_describe_path as a dict of names (host-only: no device call)."""
+    _require(entry in ENTRY, f"unknown entry {entry!r} (expected one of {sorted(ENTRY)})")
+    d = PathDesc()
+    _check(lib().qattn_describe_path(ENTRY[entry], D, fmt_of(in_dtype), _scale_mode(scaling), Skv, int(want_lse), ctypes.byref(d)), "qattn_describe_path")
+    return {n: PATH_DESC_NAMES[n][getattr(d, n)] for n, _ in PathDesc._fields_}
+
+
+def fp8_attention_forward_rowmajor(q8: torch.Tensor, k8: torch.Tensor, v16: torch.Tensor, scale_q: torch.Tensor, scale_k: torch.Tensor, *,
+                                   is_causal: bool, pv_16bit: bool = False, sm_scale: float = 0.0, precision: str = "auto",
+                                   return_lse: bool = False, lse_layout: int = LSE_NATURAL):
+    """The pybind function's contract in one C call (qattn_fp8_attention_forward_rowmajor; tk/attention.py:357-360): row-major fp8 q8
+    [B,Hq,Sq,D] / k8 [B,Hkv,Skv,D], 16-bit v16, fp32 scales -> out in v16's dtype.  pv_16bit: V and P stay 16-bit (the reference kernel's
+    numerics) instead of both GEMMs on FP8 MFMA."""
+    _require(q8.is_cuda and q8.dim() == 4 and k8.dim() == 4 and v16.dim() == 4, "q8, k8 and v16 must be 4-D device tensors")
+    _require(q8.dtype in (torch.float8_e4m3fn, torch.float8_e5m2) and k8.dtype == q8.dtype, "q8 / k8 must share an fp8 dtype")
+    _require(v16.dtype in (torch.bfloat16, torch.float16), "v16 must be bf16 or fp16")
+    q8, k8, v16 = q8.contiguous(), k8.contiguous(), v16.contiguous()
+    B, Hq, Sq, D = q8.shape
+    _require(k8.shape == v16.shape and k8.shape[0] == B and k8.shape[3] == D, "k8 / v16 shapes do not match q8")
+    Hkv, Skv = k8.shape[1], k8.shape[2]
+    _require(Hkv > 0 and Hq % Hkv == 0, f"Hq={Hq} is not a multiple of Hkv={Hkv}")
+    mode = SCALE_HEAD if scale_q.dim() == 2 else SCALE_TOKEN
+    _check_scales(scale_q, scale_k, None, mode, B, Hq, Hkv, Sq, Skv, q8.device)
+    L = lib()
+    with torch.cuda.device(q8.device):
+        out = torch.empty((B, Hq, Sq, D), dtype=v16.dtype, device=q8.device)
+        lse = torch.empty((B, Hq, L.qattn_lse_row_stride(Sq, lse_layout)), dtype=torch.float32, device=q8.device) if return_lse else None
+        ws_bytes = L.qattn_fp8_attention_rowmajor_workspace_bytes(B, Hq, Hkv, Sq, Skv, D)
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=q8.device)
+        rc = L.qattn_fp8_attention_forward_rowmajor(
+            q8.data_ptr(), k8.data_ptr(), v16.data_ptr(), out.data_ptr(), _ptr(lse), scale_q.contiguous().data_ptr(),
+            scale_k.contiguous().data_ptr(), B, Hq, Hkv, Sq, Skv, D, fmt_of(q8.dtype), fmt_of(v16.dtype),
+            fmt_of(v16.dtype) if pv_16bit else fmt_of(q8.dtype), mode, int(is_causal), float(sm_scale), _precision(precision), lse_layout,
+            ws.data_ptr(), ws_bytes, _stream(q8))
+    _check(rc, "qattn_fp8_attention_forward_rowmajor")
+    return (out, lse[..., :Sq]) if return_lse else out
+
+
 def pack16(x: torch.Tensor, layout: int) -> torch.Tensor:
     """row-major bf16/fp16 [B,H,S,D] -> flat uint8 buffer in K16FRAG / V16FRAG layout."""
     _require(x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16), "pack16 needs a 4-D bf16/fp16 device tensor")
@@ -333,11 +394,15 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
                                 fp8_dtype=torch.float8_e4m3fn, numerics: str = "compiled", sm_scale: float = 0.0,
                                 precision: str = "auto", amax_q: Optional[torch.Tensor] = None,
                                 amax_k: Optional[torch.Tensor] = None, amax_v: Optional[torch.Tensor] = None,
-                                ssq_q: Optional[torch.Tensor] = None, ssq_k: Optional[torch.Tensor] = None) -> torch.Tensor:
+                                ssq_q: Optional[torch.Tensor] = None, ssq_k: Optional[torch.Tensor] = None,
+                                return_lse: bool = False, lse_layout: int = LSE_NATURAL, return_path: bool = False):
     """16-bit q, k, v -> attention output: the quant pre-pass and the attention launch(es) in ONE C call
     (qattn_fp8_quant_attention_forward_ex); the pre-pass skips Q where the attention kernel quantises it itself.
     amax_* / ssq_*: per-head abs-max / sum of squares a producer of q, k, v already has (head-wise scaling only): the
-    abs-max launch then skips those tensors, or is skipped."""
+    abs-max launch then skips those tensors, or is skipped.
+    return_lse: also the per-row log-sum-exp [B,Hq,Sq] (the vector the reference defines, tk/attention.py:333-346), written by the same
+    launch as the output.  return_path: also the uint8 [B,Hq,Sq] PATH_* code of every row (test / debug output).
+    Returns out, or (out, lse), (out, path), (out, lse, path)."""
     B, Hq, Hkv, Sq, Skv, D = _check_qkv(q, k, v)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     L = lib()
@@ -358,13 +423,18 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         sv = torch.empty((B, Hkv), dtype=torch.float32, device=dev)
         ws_bytes = L.qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        lse = torch.empty((B, Hq, L.qattn_lse_row_stride(Sq, lse_layout)), dtype=torch.float32, device=dev) if return_lse else None
+        path = torch.empty((B, Hq, Sq), dtype=torch.uint8, device=dev) if return_path else None
         rc = L.qattn_fp8_quant_attention_forward_ex(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
             vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), _ptr(amax_q), _ptr(amax_k), _ptr(amax_v), _ptr(ssq_q),
             _ptr(ssq_k), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
-            _numerics(numerics), int(is_causal), float(sm_scale), _precision(precision), ws.data_ptr(), ws_bytes, _stream(q))
+            _numerics(numerics), int(is_causal), float(sm_scale), _precision(precision), _ptr(lse), lse_layout, _ptr(path),
+            ws.data_ptr(), ws_bytes, _stream(q))
     _check(rc, "qattn_fp8_quant_attention_forward_ex")
-    return out
+    if not (return_lse or return_path):
+        return out
+    return (out,) + ((lse[..., :Sq],) if return_lse else ()) + ((path,) if return_path else ())
 
 
 def measure_attention_clock(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, is_causal: bool = False, precision: str = "auto",

@@ -84,6 +84,7 @@ struct AttnCall {
     const void* v16;              // fused step: the original 16-bit V for the rows that see few keys (else nullptr)
     unsigned long long* stamps;   // measurement entry (else nullptr)
     bool sched_zeroed;            // fused step: the pre-pass has cleared the hand-out counters (else the launch clears them itself)
+    unsigned char* path;          // fused entry's per-row path output (else nullptr)
 };
 
 // attention workspace = [SchedState of the hand-scheduled kernel's causal launches | one flag word per (b, h, 32-row group)]
@@ -159,6 +160,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.lse_mul = a.lse_layout == QATTN_LSE_REFERENCE ? -sqrtf((float)a.D) : 1.0f;
     p.q16 = (const unsigned char*)a.q16; p.q_amax_part = a.q_amax_part; p.sq_out = a.sq_out; p.q_numerics = a.q_numerics;
     p.stamp_buf = a.stamps;
+    p.path = a.path;
     p.v16 = v_is_16 ? (const unsigned char*)a.v8 : (const unsigned char*)a.v16;
     if (a.stamps && !(a.q16 && attn_v2_covers(a.D, a.is_causal, a.scale_mode) && a.qk_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
     bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
@@ -194,7 +196,7 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     if (prof) (void)hipEventRecord(ds->prof[0], st);
     int rc = QATTN_OK;
     hipStream_t side = nullptr;
-    if (!v_is_16 && use_v2 && p.v16 != nullptr && p.q16 == nullptr && p.lse == nullptr) {
+    if (!v_is_16 && use_v2 && p.v16 != nullptr && p.q16 == nullptr) {
         // fused step on the D = 128 kernel WITHOUT in-kernel Q quantisation (fp16 inputs): its early rows through a 16-bit-V launch of
         // their own, the main launch skips those blocks (the bf16 fused step has the pass inside its kernel)
         const int n_early = pv16_early_blocks(a.Sq, a.Skv, a.is_causal, p.two_term_keys);
@@ -357,6 +359,13 @@ bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
     return D == 128 && (in_fmt == QATTN_FMT_BF16 || in_fmt == QATTN_FMT_FP16) && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
 }
 
+// fused entry: block-scaled V (one power-of-two scale per 64-key chunk) wherever the kernel's PV products take the chunk's scale byte and a
+// head has at most kMomentSplits chunks (quant_attention_impl; qattn_describe_path reports the same predicate)
+bool fused_v_block(bool fuse_q, int D, int scale_mode, int is_causal, int Skv) {
+    const bool vs_kernel = fuse_q || (scale_mode == QATTN_SCALE_HEAD && !attn_v2_covers(D, is_causal, scale_mode));
+    return vs_kernel && (Skv + 63) / 64 <= kMomentSplits;
+}
+
 }  // namespace
 
 namespace qattn {
@@ -412,6 +421,10 @@ int side_stream_join(hipStream_t st, hipStream_t side) {
     return QATTN_OK;
 }
 
+__global__ void fill_bytes_kernel(unsigned char* w, long n, unsigned char v) {   // the row_path output's pre-fill (a kernel node: see zero_words)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = v;
+}
 __global__ void zero_words_kernel(unsigned* w, long n) {   // (declared in qattn_attn.h: zero_words)
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] = 0u;
@@ -471,7 +484,7 @@ extern "C" int qattn_fp8_attention_forward(const void* q8, const void* k8, const
     const bool have_ws = workspace && workspace_bytes >= qattn_attention_workspace_bytes(B, Hq, Sq);
     if (precision == QATTN_PRECISION_AUTO && !have_ws) return QATTN_ERR_WORKSPACE;
     AttnCall a{q8, k8, v8, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v_fmt, out_fmt, scale_mode,
-               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+               is_causal, sm_scale, precision, lse_layout, have_ws ? workspace : nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, false, nullptr};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing((hipStream_t)stream)) : nullptr;
     return attention_impl(a, (hipStream_t)stream, ds);
 }
@@ -487,8 +500,10 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                                 const float* amax_q, const float* amax_k, const float* amax_v,
                                 const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
                                 int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
-                                int precision, void* workspace, size_t workspace_bytes, void* stream, unsigned long long* stamps) {
+                                int precision, float* lse, int lse_layout, unsigned char* row_path, void* workspace, size_t workspace_bytes,
+                                void* stream, unsigned long long* stamps) {
     if (!q || !k || !v || !out || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
+    if (lse_layout != QATTN_LSE_NATURAL && lse_layout != QATTN_LSE_REFERENCE) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
     if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
@@ -502,7 +517,8 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     hipStream_t st = (hipStream_t)stream;
     const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode, is_causal);
     // the measurement entry exists for one instantiation only: refuse before the pre-pass has written anything
-    if (stamps && !(fuse_q && fp8_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
+    // (the stamped instantiation exists for bf16 Q rows only: ADVICE r5)
+    if (stamps && !(fuse_q && fp8_fmt == QATTN_FMT_E4M3 && in_fmt == QATTN_FMT_BF16)) return QATTN_ERR_UNSUPPORTED_FMT;
     // (Tried and dropped, profiles/r02_overlap.md: running the HBM-bound pre-pass of batch group g+1 on a second stream beside
     // the attention of group g.  The 512-thread attention workgroups leave 32-48 VGPRs per SIMD, the pre-pass waves displace
     // them instead of sharing the CU, and the chip is power-limited on the attention kernel: the step got 19-31 % SLOWER.)
@@ -518,11 +534,10 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     // block-scaled V with head-wise scales wherever the kernel's PV products take the chunk's scale byte -- the hand-scheduled
     // D = 128 kernel in its fused-Q instantiation, the templated kernel (D = 64 / 256) -- and a head has at most kMomentSplits
     // chunks: V then needs no abs-max pass
-    const bool vs_kernel = fuse_q || (scale_mode == QATTN_SCALE_HEAD && !attn_v2_covers(D, is_causal, scale_mode));
 #ifdef QATTN_DEV
-    const bool v_block = vs_kernel && (Skv + 63) / 64 <= kMomentSplits && !getenv("QATTN_NO_VBLOCK") && dev_env().variant == 2;
+    const bool v_block = fused_v_block(fuse_q, D, scale_mode, is_causal, Skv) && !getenv("QATTN_NO_VBLOCK") && dev_env().variant == 2;
 #else
-    const bool v_block = vs_kernel && (Skv + 63) / 64 <= kMomentSplits;
+    const bool v_block = fused_v_block(fuse_q, D, scale_mode, is_causal, Skv);
 #endif
     const float* ext_amax[3] = {amax_q, amax_k, amax_v};
     // the hand-out counters of the attention launch (D = 128 kernel) are cleared by the quantise pass on its way: a launch of
@@ -535,15 +550,20 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                               numerics, ws, fuse_q, moments, v_block, st, ext_amax, zero_in_prepass && zero_bytes ? (unsigned*)attn_ws : nullptr,
                               zero_in_prepass ? (int)(zero_bytes / sizeof(unsigned)) : 0);
     if (rc != QATTN_OK) return rc;
+    if (row_path) {   // every row starts as "one-term fp8-V sweep"; the other passes overwrite what they store
+        const long n = (long)B * Hq * Sq;
+        hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, row_path, n, (unsigned char)QATTN_PATH_ONE_TERM);
+        if (hipGetLastError() != hipSuccess) return QATTN_ERR_LAUNCH;
+    }
     const QuantMoments mom = quant_moments(ws, B, Hq, Hkv, Sq, Skv, D);
     const bool q_ext = amax_q != nullptr;
-    AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, nullptr, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
-               fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, QATTN_LSE_NATURAL, attn_ws,
+    AttnCall a{fuse_q ? nullptr : q8, k8, v8, out, lse, fuse_q ? nullptr : scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D,
+               fp8_fmt, fp8_fmt, in_fmt, scale_mode, is_causal, sm_scale, precision, lse_layout, attn_ws,
                v_block ? mom.vexp : nullptr,
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, v, stamps, zero_in_prepass};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, v, stamps, zero_in_prepass, row_path};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }
@@ -553,9 +573,11 @@ extern "C" int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k
                                                     const float* amax_q, const float* amax_k, const float* amax_v,
                                                     const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
                                                     int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
-                                                    int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                                                    int precision, float* lse, int lse_layout, unsigned char* row_path, void* workspace,
+                                                    size_t workspace_bytes, void* stream) {
     return quant_attention_impl(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, amax_q, amax_k, amax_v, ssq_q, ssq_k, B, Hq, Hkv,
-                                Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, workspace, workspace_bytes, stream, nullptr);
+                                Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, lse, lse_layout, row_path, workspace,
+                                workspace_bytes, stream, nullptr);
 }
 
 extern "C" size_t qattn_attention_stamp_bytes(int B, int Hq, int Sq) {
@@ -570,8 +592,8 @@ extern "C" int qattn_fp8_quant_attention_forward_stamped(const void* q, const vo
                                                          size_t workspace_bytes, void* stamps, size_t stamps_bytes, void* stream) {
     if (!stamps || stamps_bytes < qattn_attention_stamp_bytes(B, Hq, Sq)) return QATTN_ERR_WORKSPACE;
     return quant_attention_impl(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, nullptr, nullptr, nullptr, nullptr, nullptr, B, Hq,
-                                Hkv, Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, workspace, workspace_bytes, stream,
-                                (unsigned long long*)stamps);
+                                Hkv, Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, nullptr, QATTN_LSE_NATURAL, nullptr,
+                                workspace, workspace_bytes, stream, (unsigned long long*)stamps);
 }
 
 extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8,
@@ -581,5 +603,80 @@ extern "C" int qattn_fp8_quant_attention_forward(const void* q, const void* k, c
                                                  size_t workspace_bytes, void* stream) {
     return qattn_fp8_quant_attention_forward_ex(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, nullptr, nullptr, nullptr,
                                                 nullptr, nullptr, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal,
-                                                sm_scale, precision, workspace, workspace_bytes, stream);
+                                                sm_scale, precision, nullptr, QATTN_LSE_NATURAL, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ---- the pybind function's contract in ONE call (tk/attention.py:357-360, 419-437): row-major fp8 q / k, 16-bit v, fp32 scales -> out
+extern "C" size_t qattn_fp8_attention_rowmajor_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Skv, int D) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0 || (D != 64 && D != 128 && D != 256)) return 0;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    return up(qattn_fp8_tensor_bytes(QATTN_LAYOUT_KFRAG, B, Hkv, Skv, D)) + up(qattn_fp8_tensor_bytes(QATTN_LAYOUT_VFRAG, B, Hkv, Skv, D)) +
+           up(sizeof(float) * (size_t)B * Hkv) + up(qattn_quant_workspace_bytes(B, Hkv, Skv, D, QATTN_SCALE_HEAD)) + up(qattn_attention_workspace_bytes(B, Hq, Sq));
+}
+
+extern "C" int qattn_fp8_attention_forward_rowmajor(const void* q8, const void* k8, const void* v16, void* out, float* lse, const float* scale_q,
+                                                    const float* scale_k, int B, int Hq, int Hkv, int Sq, int Skv, int D, int qk_fmt, int v16_fmt,
+                                                    int pv_fmt, int scale_mode, int is_causal, float sm_scale, int precision, int lse_layout,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!q8 || !k8 || !v16 || !out || !scale_q || !scale_k) return QATTN_ERR_INVALID_ARG;
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    if ((D != 64 && D != 128 && D != 256) || Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (qk_fmt != QATTN_FMT_E4M3 && qk_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (v16_fmt != QATTN_FMT_BF16 && v16_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (pv_fmt != qk_fmt && pv_fmt != v16_fmt) return QATTN_ERR_UNSUPPORTED_FMT;   // both GEMMs on FP8 MFMA, or the reference's 16-bit P.V
+    if (!workspace || workspace_bytes < qattn_fp8_attention_rowmajor_workspace_bytes(B, Hq, Hkv, Sq, Skv, D)) return QATTN_ERR_WORKSPACE;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    unsigned char* w = (unsigned char*)workspace;
+    void* kfrag = w;                w += up(qattn_fp8_tensor_bytes(QATTN_LAYOUT_KFRAG, B, Hkv, Skv, D));
+    void* vfrag = w;                w += up(qattn_fp8_tensor_bytes(QATTN_LAYOUT_VFRAG, B, Hkv, Skv, D));
+    float* scale_v = (float*)w;     w += up(sizeof(float) * (size_t)B * Hkv);
+    void* quant_ws = w;             const size_t quant_ws_bytes = qattn_quant_workspace_bytes(B, Hkv, Skv, D, QATTN_SCALE_HEAD);
+    w += up(quant_ws_bytes);
+    void* attn_ws = w;              const size_t attn_ws_bytes = qattn_attention_workspace_bytes(B, Hq, Sq);
+    // K: a byte permutation into the MFMA fragment order (the reference launcher's `.contiguous()`, tk/attention.py:419-421, is the analogue)
+    int rc = qattn_pack_fp8(k8, kfrag, B, Hkv, Skv, D, QATTN_LAYOUT_KFRAG, stream);
+    if (rc != QATTN_OK) return rc;
+    if (pv_fmt == qk_fmt) {   // V quantised head-wise with the reference quantiser's sequence (nn.py:14-19) straight into fragment order
+        rc = qattn_quant_fp8(v16, v16_fmt, vfrag, scale_v, B, Hkv, Skv, D, qk_fmt, QATTN_SCALE_HEAD, QATTN_NUMERICS_COMPILED, QATTN_LAYOUT_VFRAG,
+                             quant_ws, quant_ws_bytes, stream);
+        if (rc != QATTN_OK) return rc;
+        return qattn_fp8_attention_forward(q8, kfrag, vfrag, out, lse, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, qk_fmt, qk_fmt, v16_fmt,
+                                           scale_mode, is_causal, sm_scale, precision, lse_layout, attn_ws, attn_ws_bytes, stream);
+    }
+    return qattn_fp8_attention_forward(q8, kfrag, v16, out, lse, scale_q, scale_k, nullptr, B, Hq, Hkv, Sq, Skv, D, qk_fmt, v16_fmt, v16_fmt, scale_mode,
+                                       is_causal, sm_scale, precision, lse_layout, attn_ws, attn_ws_bytes, stream);
+}
+
+// ---- which numerics an entry runs for given arguments: host-only, from the very predicates the dispatch above uses
+extern "C" int qattn_describe_path(int entry, int D, int in_fmt, int scale_mode, int Skv, int want_lse, qattn_path_desc* d) {
+    if (!d) return QATTN_ERR_INVALID_ARG;
+    if (entry != QATTN_ENTRY_SEPARATE && entry != QATTN_ENTRY_SEPARATE_V16 && entry != QATTN_ENTRY_FUSED) return QATTN_ERR_INVALID_ARG;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    memset(d, 0, sizeof(*d));
+    const bool v2 = attn_v2_covers(D, 0, scale_mode);
+    if (entry == QATTN_ENTRY_SEPARATE_V16) {   // attention_impl: v_is_16 -> launch_attn_pv16 for every row
+        d->kernel = QATTN_KERNEL_PV16; d->q_quant = QATTN_QQUANT_CALLER; d->v_format = QATTN_VFORMAT_16BIT; d->sweep_p = QATTN_SWEEP_P16;
+        d->precise = QATTN_PRECISE_NONE; d->early = QATTN_EARLY_NONE; d->start_mode = QATTN_START_NONE; d->lse = QATTN_LSE_SRC_EXACT;
+        return QATTN_OK;
+    }
+    d->kernel = v2 ? QATTN_KERNEL_V2 : QATTN_KERNEL_V4;
+    if (entry == QATTN_ENTRY_SEPARATE) {   // qattn_fp8_attention_forward / _rowmajor with an fp8 V: no 16-bit V at hand
+        d->q_quant = QATTN_QQUANT_CALLER; d->v_format = QATTN_VFORMAT_HEAD;
+        d->sweep_p = want_lse ? QATTN_SWEEP_EXACT : QATTN_SWEEP_BYTE;   // launch_attn_v2_t / launch_v4_full_d: byte_exp = lse == nullptr
+        d->precise = QATTN_PRECISE_TWO_TERM; d->early = QATTN_EARLY_TWO_TERM; d->start_mode = QATTN_START_KEYS; d->lse = QATTN_LSE_SRC_EXACT;
+        return QATTN_OK;
+    }
+    const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode, 0);
+    d->q_quant = fuse_q ? QATTN_QQUANT_KERNEL : QATTN_QQUANT_PREPASS;
+    d->v_format = fused_v_block(fuse_q, D, scale_mode, 0, Skv) ? QATTN_VFORMAT_BLOCK : QATTN_VFORMAT_HEAD;
+    // the fused D = 128 kernel is byte-exponential whatever is asked (launch_attn_v2_t: p.q16 != nullptr); the templated one switches
+    d->sweep_p = (fuse_q || !want_lse) ? QATTN_SWEEP_BYTE : QATTN_SWEEP_EXACT;
+    d->precise = fuse_q ? QATTN_PRECISE_V16 : QATTN_PRECISE_TWO_TERM;            // run_block kPass16 / launch_v4_full_d's two-term launches
+    d->early = fuse_q ? QATTN_EARLY_V16_INLINE : QATTN_EARLY_V16_LAUNCH;          // pv16p_block_pass inside the kernel / launch_attn_pv16 beside it
+    d->start_mode = scale_mode == QATTN_SCALE_HEAD ? QATTN_START_MOMENTS : QATTN_START_KEYS;   // quant_attention_impl: auto_head
+    d->lse = fuse_q ? QATTN_LSE_SRC_QUANTISED : QATTN_LSE_SRC_EXACT;
+    return QATTN_OK;
 }

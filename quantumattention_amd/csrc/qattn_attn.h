@@ -141,6 +141,11 @@ struct AttnParams {
     float* sq_out;                 // fused step: scale_q [B,Hq] is written by the attention kernel
     int q_numerics;
     unsigned long long* stamp_buf;   // measurement entry only (else nullptr): {shader cycles, 100 MHz ticks} of every wave's KV sweep
+    // Debug output of the fused entry (else nullptr): one byte per query row [B,Hq,Sq], pre-filled with QATTN_PATH_ONE_TERM by the call; every
+    // pass that is NOT the one-term fp8-V sweep overwrites the rows it stores: QATTN_PATH_TWO_TERM (two-term fp8 P on the fp8 V: rescued
+    // rows, two-term blocks of the templated kernel) or QATTN_PATH_V16 (16-bit P on the caller's 16-bit V: early blocks, blocks on the
+    // 16-bit-V pass, severely peaked rescued rows).  The one-term sweeps never touch it.
+    unsigned char* path;
 #ifdef QATTN_DEV
     int waves;       // waves per workgroup of the v2 kernel (8 or 4): nqb is computed for waves*32 rows
     int lds_pad;     // force this dynamic-LDS size (occupancy experiments), 0 = natural
@@ -698,6 +703,7 @@ __device__ __forceinline__ void rescue_rows_at(const AttnParams& p, unsigned cha
         store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + row, hh, store && row < p.Sq);
         if (p.lse && hh == 0 && store && row < p.Sq)
             p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
+        if (p.path && hh == 0 && store && row < p.Sq) p.path[bh * p.Sq + row] = (unsigned char)QATTN_PATH_TWO_TERM;
     }
 }
 

@@ -869,6 +869,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             const float lse = 0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot);
             p.lse[bh * p.lse_stride + qrow] = lse * p.lse_mul;
         }
+        if (TWO && p.path && hh == 0) p.path[bh * p.Sq + qrow] = (unsigned char)QATTN_PATH_TWO_TERM;   // (one-term sweeps leave the call's pre-fill)
     }
     return 0;
 }
@@ -1380,8 +1381,14 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes + the Q prefetch's dump slot
     if (Q16 && NW == 8) lds = (size_t)kLdsAll;   // the fused kernels: the pipelined 16-bit-V pass's ring (5 x 24 KiB), the 16-bit-V rescue's V areas + parked Q^T fragments (all 160 KiB), the words at the end (v2_words_offset)
     static_assert(kP16Stages * (64 * 128 + 64 * 2 * 128) <= kLdsAll - 4096 && kStagesV2 * 2 * 64 * 128 + 8 * kQPerWave * 128 <= kLdsAll - 4096, "the rings stay clear of the words");
+    //  the fused kernels' words -- 16 vote / mailbox words, kVxWords V scale words, the 1 KiB dump slot -- live in the last 4 KiB, which
+    // the 16-bit-V rescue's parked Q^T fragments (wave 7's slot, behind its eight V areas) deliberately cover: rescue_pass takes the masks and
+    // the kernel's block loop the drawn successor OUT before anything is parked there (read-before-clobber, see their comments)
+    static_assert(kRescue16VBytes + 8 * kQPerWave * 128 == kLdsAll, "the 16-bit-V rescue's V areas + parked Q^T fragments fill the CU's LDS exactly");
+    static_assert(64 + 4 * kVxWords + 1024 <= 4096, "vote words + V scale words + dump slot fit the last 4 KiB");
+    static_assert(QATTN_QPREFETCH == 0 || !Q16, "the Q prefetch's dump slot overlaps wave 7's parked Q^T fragments in the fused kernels");
 #ifdef QATTN_DEV
-    if (p.lds_pad > 0) lds = (size_t)p.lds_pad;
+    if (p.lds_pad > 0 && !(Q16 && NW == 8 && p.lds_pad < kLdsAll)) lds = (size_t)p.lds_pad;   // (the fused kernels' words sit at kLdsAll - 4096: no smaller allocation)
 #endif
 #ifdef QATTN_DEV
     if (CHECK && !CAUSAL && BYTE && NW == 8 && getenv("QATTN_ABL_NONEFF")) {   // dev: the AUTO kernel without the effective-key-count MFMA

@@ -355,6 +355,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     store_o_rows<MB>(p.out, p.out_fmt, o, inv, bh * p.Sq + qrow, hh, qrow < p.Sq);
     if (!BYTE && p.lse && hh == 0 && qrow < p.Sq)  // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l')
         p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
+    if (!BYTE && two && p.path && hh == 0 && qrow < p.Sq) p.path[bh * p.Sq + qrow] = (unsigned char)QATTN_PATH_TWO_TERM;   // (fused entry's debug output)
 }
 
 template <int D, int FMT, bool CAUSAL, bool TOKEN, bool BYTE>
@@ -510,7 +511,7 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
     // the fused step (D = 64 / 256, and D = 128 with token-wise scales): the query blocks that see fewer than two_term_keys keys attend the ORIGINAL
     // 16-bit V with 16-bit P (qattn_pv16.h) instead of two-term fp8 P on the fp8 V; the rest of rows_two (ACCURATE) stays two-term
     int rows_early = 0;
-    if (p.v16 != nullptr && p.lse == nullptr) {
+    if (p.v16 != nullptr) {   // (with an LSE output too: pv16_block_pass writes its rows' entries)
         rows_early = min(rows_two, pv16_early_blocks(p.Sq, p.Skv, causal, p.two_term_keys) * 256);
         if (rc == QATTN_OK && rows_early > 0) rc = launch_attn_pv16(p, D, fmt, p.out_fmt, causal, scale_mode, st_e, rows_early / 256);
     }

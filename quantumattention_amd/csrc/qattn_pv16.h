@@ -554,6 +554,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
 #ifndef QATTN_PV16_STAMP
     if (p.lse && hh == 0 && qvalid) p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c) + __logf(l_tot)) * p.lse_mul;
 #endif
+    if (p.path && hh == 0 && qvalid) p.path[bh * p.Sq + qrow] = (unsigned char)QATTN_PATH_V16;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -750,7 +751,11 @@ __device__ __forceinline__ void rescue_rows16_at(const AttnParams& p, unsigned c
         }
         __syncthreads();
     }
-    if (wave == 0) store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_run, bh * p.Sq + row, hh, store && row < p.Sq);
+    if (wave == 0) {
+        store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_run, bh * p.Sq + row, hh, store && row < p.Sq);
+        if (p.lse && hh == 0 && store && row < p.Sq) p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c) + __logf(l_run)) * p.lse_mul;
+        if (p.path && hh == 0 && store && row < p.Sq) p.path[bh * p.Sq + row] = (unsigned char)QATTN_PATH_V16;
+    }
 }
 
 // The 16-bit-V form of qattn_fp8_attention_forward (v_fmt = QATTN_FMT_BF16 / _FP16): every query block through pv16_block_pass, one

@@ -468,6 +468,9 @@ __device__ __forceinline__ void pv16p_block_pass(const AttnParams& p, unsigned c
     const unsigned ticket = draw_issue_hook();
     store_o_rows<MB>(p.out, p.out_fmt, st.o, 1.0f / l_tot, bh * p.Sq + qrow, hh, qvalid);
     draw_finish_hook(ticket);
+    // optional outputs of the fused entry (ABI 7): the log-sum-exp row (the sums are of the ROUNDED 16-bit P, pv16_block_pass) and the row's path
+    if (p.lse && hh == 0 && qvalid) p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (st.m_run * st.c) + __logf(l_tot)) * p.lse_mul;
+    if (p.path && hh == 0 && qvalid) p.path[bh * p.Sq + qrow] = (unsigned char)QATTN_PATH_V16;
 }
 
 }  // namespace qattn

@@ -95,20 +95,14 @@ def fp8_attention_forward(
     reason = scale_shapes_reason(query, key, scale_q, scale_k)
     if reason:
         raise RuntimeError(reason)
-    scaling = "head-wise" if scale_q.dim() == 2 else "token-wise"
-    k_frag = _native.pack_fp8(key, _native.LAYOUT_KFRAG)
-    if config.attention.pv_precision == "16bit":
-        # the reference kernel's own numerics: value stays 16-bit, P is cast to 16 bit (tk/attention.py:72,286,318)
-        v_frag, scale_v = value, None
-    else:
-        if config.attention.pv_precision not in ("fp8", "16bit"):
-            raise ValueError(f"Unsupported config.attention.pv_precision: {config.attention.pv_precision!r} (expected 'fp8' or '16bit')")
-        v_frag, scale_v = _native.quant_fp8(value, scaling="head-wise", fp8_dtype=query.dtype,
-                                            layout=_native.LAYOUT_VFRAG)
-    return _native.fp8_attention_forward(
-        query, k_frag, v_frag, scale_q, scale_k, scale_v, Hkv=Hkv, Skv=Skv, out_dtype=value.dtype,
-        is_causal=is_causal, scaling=scaling, sm_scale=0.0 if scale is None else float(scale),
-        precision=config.attention.precision)
+    if config.attention.pv_precision not in ("fp8", "16bit"):
+        raise ValueError(f"Unsupported config.attention.pv_precision: {config.attention.pv_precision!r} (expected 'fp8' or '16bit')")
+    # ONE C call with the pybind function's contract (tk/attention.py:357-360): the K re-lay and the V handling happen inside, in a
+    # workspace.  pv_precision = "16bit": the reference kernel's own numerics, value stays 16-bit and P is cast to 16 bit
+    # (tk/attention.py:72,286,318); "fp8" (default): V quantised head-wise, both GEMMs on FP8 MFMA.
+    return _native.fp8_attention_forward_rowmajor(
+        query, key, value, scale_q, scale_k, is_causal=is_causal, pv_16bit=config.attention.pv_precision == "16bit",
+        sm_scale=0.0 if scale is None else float(scale), precision=config.attention.precision)
 
 
 @_register_fake("quantumattention_amd::fp8_attention_forward")

@@ -28,7 +28,59 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert getattr(L, n) is not None, n
     lib = _native.lib()
-    assert lib.qattn_abi_version() == _native.ABI_VERSION == 6
+    assert lib.qattn_abi_version() == _native.ABI_VERSION == 7
+
+
+def _path_table_rows():
+    """The rows of include/qattn.h's PATH TABLE: dicts of the header's column names."""
+    text = open(os.path.join(ROOT, "include", "qattn.h")).read()
+    lines = [ln.strip()[1:].strip() for ln in text.splitlines() if ln.strip().startswith("* |")]
+    cells = [[c.strip() for c in ln.strip("|").split("|")] for ln in lines]
+    head, rows = cells[0], [c for c in cells[1:] if not set(c[0]) <= set("-")]
+    assert head == ["entry", "D", "scales", "Skv", "kernel", "q_quant", "v_format", "sweep_p", "precise", "early", "start", "lse"], head
+    return [dict(zip(head, r)) for r in rows]
+
+
+def test_path_table_matches_dispatch():
+    """ONE table (entry x D x scales x Skv -> kernel, Q quantisation, V format, P format, precise pass, early rows,
+    start-mode source, LSE source) in include/qattn.h, walked against the host-only query qattn_describe_path(), which answers from the
+    predicates the dispatch in csrc/qattn_api.hip itself uses (q_fusion_ok, fused_v_block, attn_v2_covers).  Every combination of the
+    arguments must be covered by exactly one row, and the row must say what the library says."""
+    rows = _path_table_rows()
+    assert len(rows) == 9
+    def covers(r, entry, D, scaling, Skv):
+        return (r["entry"] == entry and (r["D"] == "any" or str(D) in r["D"].split(",")) and r["scales"] in ("any", scaling.split("-")[0])
+                and {"any": True, "<=16384": Skv <= 16384, ">16384": Skv > 16384}[r["Skv"]])
+
+    seen = set()
+    for entry in ("fused", "separate", "separate16"):
+        for D in (64, 128, 256):
+            for scaling in ("head-wise", "token-wise"):
+                for dtype in (torch.bfloat16, torch.float16):
+                    for Skv in (1, 64, 1000, 4096, 16384, 16385, 20000, 100000):
+                        match = [r for r in rows if covers(r, entry, D, scaling, Skv)]
+                        assert len(match) == 1, (entry, D, scaling, Skv, match)
+                        row = match[0]
+                        seen.add(id(row))
+                        for want_lse in (False, True):
+                            got = _native.describe_path(entry, D, dtype, scaling, Skv, want_lse)
+                            lse_col = row["lse"]
+                            want = {"kernel": row["kernel"], "q_quant": row["q_quant"], "v_format": row["v_format"], "precise": row["precise"],
+                                    "early": row["early"], "start_mode": row["start"], "lse": lse_col.rstrip("*"),
+                                    # `exact*`: asking for the LSE switches the sweep to exact exponentials
+                                    "sweep_p": "exact" if (want_lse and lse_col.endswith("*")) else row["sweep_p"]}
+                            assert got == want, (entry, D, scaling, dtype, Skv, want_lse, got, want)
+    assert len(seen) == len(rows), "a row of the table is never reached"
+    # argument errors: codes, no device call
+    d = _native.PathDesc()
+    L = _native.lib()
+    assert L.qattn_describe_path(2, 96, 2, 0, 100, 0, ctypes.byref(d)) == -2 and L.qattn_describe_path(7, 128, 2, 0, 100, 0, ctypes.byref(d)) == -1
+    assert L.qattn_describe_path(2, 128, 0, 0, 100, 0, ctypes.byref(d)) == -3 and L.qattn_describe_path(2, 128, 2, 0, 100, 0, None) == -1
+
+
+def test_header_stays_within_its_size_budget():
+    """The table replaces prose: include/qattn.h <= 16 kB."""
+    assert os.path.getsize(os.path.join(ROOT, "include", "qattn.h")) <= 16 * 1024
 
 
 def test_abi_size_queries_and_error_codes_need_no_gpu():

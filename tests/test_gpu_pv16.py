@@ -19,7 +19,8 @@ import oracle
 import quantumattention_amd as qa
 from quantumattention_amd import _native
 from tests.conftest import GOLDEN, golden_files
-from tests.gpu_utils import FMT, TDT, bits16, bits8, err_stats, fmt16, from_bits16, oracle_for_fp8_path, out_to_f32
+from tests.gpu_utils import (FMT, PATH_ONE_TERM, PATH_V16, TDT, assert_within_bound, bits16, bits8, check_path_structure, err_stats, fmt16, from_bits16, fused_call,
+                             oracle_for_fp8_path, out_to_f32)
 
 pytestmark = pytest.mark.gpu
 TOL16 = 2.0 ** -7
@@ -122,18 +123,21 @@ def test_fused_step_attends_the_16bit_v_on_rows_that_see_few_keys(S, D):
     q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
     q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
     k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
-    got = out_to_f32(qa.fp8_attn_func(q, k, v, is_causal=True))
+    got, path = fused_call(q, k, v, causal=True)
+    np.testing.assert_array_equal(got, out_to_f32(qa.fp8_attn_func(q, k, v, is_causal=True)))   # (the public call: row_path = NULL)
     np.testing.assert_array_equal(got[:, :, 0], v[:, :, 0].float().cpu().numpy())   # softmax over one key: the output IS that value row
     ref16 = oracle.attention_forward(q8, k8, bits16(v), oracle.FMT_E4M3, oracle.FMT_E4M3, oracle.FMT_BF16, sq, sk, None, causal=True)
     n_early = min(S, 1024)   # blocks 0..3: first rows 0, 256, 512, 768 see < 1024 keys
+    assert (path[:, :, :n_early] == PATH_V16).all()
+    check_path_structure(path, S, S, True, "auto", D == 128)
     mx, rmse = err_stats(got[:, :, :n_early], ref16[:, :, :n_early])
     assert mx < _tol(ref16), (mx, rmse)
-    mixed = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=True, v_block=True)
-    mx_all, _ = err_stats(got, mixed)
-    assert mx_all < 2.0 ** -6 * max(1.0, float(np.abs(mixed).max()) / 2.0), mx_all
+    both = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=True, v_block=True)
+    assert_within_bound(got, both, path)    # every row against the oracle of ITS path
     # non-causal with fewer than 1024 keys: every block takes the pass
     if S < 1024:
-        got_nc = out_to_f32(qa.fp8_attn_func(q, k, v, is_causal=False))
+        got_nc, path_nc = fused_call(q, k, v, causal=False)
+        assert (path_nc == PATH_V16).all()
         ref_nc = oracle.attention_forward(q8, k8, bits16(v), oracle.FMT_E4M3, oracle.FMT_E4M3, oracle.FMT_BF16, sq, sk, None, causal=False)
         mx_nc, _ = err_stats(got_nc, ref_nc)
         assert mx_nc < _tol(ref_nc), mx_nc
@@ -149,7 +153,8 @@ def test_causal_call_with_more_rows_than_keys_and_few_keys_runs_every_block_on_t
     k, v = (torch.randn(B, H, Skv, D, dtype=torch.bfloat16, device="cuda") for _ in range(2))
     q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
     k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
-    got = out_to_f32(qa.fp8_attn_func(q, k, v, is_causal=True))
+    got, path = fused_call(q, k, v, causal=True)
+    assert (path == PATH_V16).all()
     ref16 = oracle.attention_forward(q8, k8, bits16(v), oracle.FMT_E4M3, oracle.FMT_E4M3, oracle.FMT_BF16, sq, sk, None, causal=True)
     mx, _ = err_stats(got, ref16)
     assert mx < _tol(ref16), mx
