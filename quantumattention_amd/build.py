@@ -18,9 +18,8 @@ BUILD = os.path.join(HERE, "_build")
 # directory of its own that neither git nor gpurun ships (.gitignore, .gpurunignore); the objects of the shipped library do not
 BUILD_TEMPS = os.path.join(HERE, "_build_temps")
 LIB = os.path.join(HERE, "libqattn_hip.so")
-# the dev library (ablations, cycle stamps, QATTN_* environment switches) is a tool: it lives beside the A/B baselines, not
-# beside the product library
-DEV_LIB = os.path.join(os.path.dirname(HERE), "tools", "ab_libs", "libqattn_dev.so")
+# A/B baselines and tuning variants (`--variant=`) live in tools/ab_libs/, not beside the product library
+AB_LIBS = os.path.join(os.path.dirname(HERE), "tools", "ab_libs")
 SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_attn16.hip", "qattn_api.hip", "qattn_probe.hip", "qattn_attn_pv16.hip"]
 # (source, extra flags, object name): the two big kernel files are compiled once per operand format / head dimension so that
 # the build runs in parallel (the longest single translation unit sets the wall time)
@@ -40,8 +39,9 @@ UNITS = [
     ("qattn_probe.hip", [], "qattn_probe"),
     ("qattn_attn_pv16.hip", [], "qattn_attn_pv16"),
 ]
-# `--dev` builds tools/ab_libs/libqattn_dev.so with -DQATTN_DEV: timing-only ablation instantiations, in-kernel cycle stamps, the
-# QATTN_* environment switches.  The product library contains none of them.
+# (Until round 5 `--dev` built a second library with -DQATTN_DEV: timing-only ablation instantiations, per-segment cycle stamps, work logs and
+# QATTN_* environment switches.  Round 6 took that scaffolding out of the sources -- identical product ISA, profiles/r06/isa_identity_*.log;
+# the measurements it produced are in profiles/r01 .. r05 and docs/.  What remains for experiments: `--variant=<name> -DKNOB=value`.)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-ffp-contract=off", "-Wall", "-Wno-unused-command-line-argument", "-Wno-unused-value", "-Wno-pass-failed"]
@@ -61,31 +61,28 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = False, dev: bool = False, variant: str = "",
-          extra_defines=()) -> str:
+def build(force: bool = False, save_temps: bool = False, verbose: bool = False, variant: str = "", extra_defines=()) -> str:
     """Compile what is stale and link the library; returns its path.  save_temps: compile every unit with -save-temps into
     BUILD_TEMPS instead (same flags, same code; the library is left alone) and return that directory.
     variant / extra_defines (development): a library of its own, tools/ab_libs/libqattn_<variant>.so, compiled with the given -D macros
     (kernel tuning knobs) for A/B runs with tools/ab.py or tools/kstats.sh."""
     extra_defines = sorted(extra_defines)
-    if save_temps and (variant or extra_defines or dev):
+    if save_temps and (variant or extra_defines):
         # BUILD_TEMPS is what the resource / hazard tests read: only the product configuration may write there
-        raise ValueError("save_temps is for the product configuration only (no variant, no -D macros, no --dev)")
+        raise ValueError("save_temps is for the product configuration only (no variant, no -D macros)")
     if extra_defines and not variant:
-        raise ValueError("-D macros need --variant=<name>: the product and dev libraries are built without tuning macros")
+        raise ValueError("-D macros need --variant=<name>: the product library is built without tuning macros")
     # the macros are part of the object directory's name: another set of -D values never reuses stale objects
     tag = ("_" + hashlib.sha1(" ".join(extra_defines).encode()).hexdigest()[:8]) if extra_defines else ""
-    build_dir = BUILD_TEMPS if save_temps else BUILD + ("_dev" if dev else "") + (f"_var_{variant}{tag}" if variant else "")
-    lib = DEV_LIB if dev else LIB
-    if variant or dev:
-        os.makedirs(os.path.dirname(DEV_LIB), exist_ok=True)
+    build_dir = BUILD_TEMPS if save_temps else BUILD + (f"_var_{variant}{tag}" if variant else "")
+    lib = LIB
     if variant:
-        lib = os.path.join(os.path.dirname(HERE), "tools", "ab_libs", f"libqattn_{variant}.so")
-        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        os.makedirs(AB_LIBS, exist_ok=True)
+        lib = os.path.join(AB_LIBS, f"libqattn_{variant}.so")
     os.makedirs(build_dir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "qattn.h"))
+    headers += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("qattn.h", "qattn_measure.h")]
     objs, jobs = [], []
     for src, defines, name in UNITS:
         s = os.path.join(CSRC, src)
@@ -98,7 +95,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
                 text = "".join(f"#define {d}\n" for d in defines) + f'#include "{s}"\n'
                 if not os.path.exists(unit) or open(unit).read() != text:
                     open(unit, "w").write(text)
-            cmd = [hipcc] + FLAGS + (["-DQATTN_DEV"] if dev else []) + [f"-D{d}" for d in extra_defines] + ["-c", unit, "-o", o]
+            cmd = [hipcc] + FLAGS + [f"-D{d}" for d in extra_defines] + ["-c", unit, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)
@@ -117,5 +114,4 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False, 
 
 if __name__ == "__main__":
     var = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")
-    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True, dev="--dev" in sys.argv,
-                variant=var, extra_defines=[a[2:] for a in sys.argv if a.startswith("-D")]))
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True, variant=var, extra_defines=[a[2:] for a in sys.argv if a.startswith("-D")]))

@@ -3,10 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#ifdef QATTN_DEV
 #include <algorithm>
-#include <vector>
-#endif
 
 #include "qattn_attn.h"
 #include "qattn_pv16.h"
@@ -14,26 +11,6 @@
 using namespace qattn;
 
 namespace {
-
-#ifdef QATTN_DEV
-// Development switches (only in `build.py --dev` libraries; the product library reads no environment variable):
-//   QATTN_KERNEL_VARIANT=4  the templated kernel (qattn_attn_v4.hip) for D = 128 too
-//   QATTN_EXACT_EXP=1       exact v_exp_f32 + RNE conversion instead of the byte exponential
-//   QATTN_V2_WAVES / QATTN_V2_LDS / QATTN_V2_DBG / QATTN_TWO_TERM_KEYS / QATTN_PEAK_R0 / QATTN_NO_Q_FUSION
-struct DevEnv {
-    int variant, exact_exp, waves, lds, dbg, two_term_keys, no_q_fusion, causal_group;
-    float peak_r0;
-    DevEnv() {
-        auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
-        variant = geti("QATTN_KERNEL_VARIANT", 2); exact_exp = geti("QATTN_EXACT_EXP", 0); waves = geti("QATTN_V2_WAVES", 8);
-        lds = geti("QATTN_V2_LDS", 0); dbg = geti("QATTN_V2_DBG", 0); two_term_keys = geti("QATTN_TWO_TERM_KEYS", kTwoTermKeys);
-        no_q_fusion = geti("QATTN_NO_Q_FUSION", 0); causal_group = geti("QATTN_CAUSAL_GROUP", 0);
-        const char* e = getenv("QATTN_PEAK_R0");
-        peak_r0 = e ? (float)atof(e) : kPeakR0;
-    }
-};
-const DevEnv& dev_env() { static const DevEnv e; return e; }   // read once, at the first call
-#endif
 
 // Per-device events of the bench.py measurement aid (qattn_profile_attention), created on first use.
 constexpr int kMaxDevices = 64;
@@ -146,7 +123,6 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.max_rescue_rows = kMaxRescueRows;
     p.persistent = 1;
     p.dyn_min_rounds = kDynMinRounds;
-    p.no_forecast = 0;
     p.ssq_q = a.precision == QATTN_PRECISION_AUTO ? a.ssq_q : nullptr;   // (FAST: the caller vouches for flat rows)
     p.ssq_k = p.ssq_q ? a.ssq_k : nullptr;
     p.vexp = a.vexp;
@@ -163,199 +139,24 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.path = a.path;
     p.v16 = v_is_16 ? (const unsigned char*)a.v8 : (const unsigned char*)a.v16;
     if (a.stamps && !(a.q16 && attn_v2_covers(a.D, a.is_causal, a.scale_mode) && a.qk_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
-    bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
-#ifdef QATTN_DEV
-    const DevEnv& e = dev_env();
-    p.exact_exp = e.exact_exp;
-    p.two_term_keys = e.two_term_keys;
-    if (a.precision == QATTN_PRECISION_AUTO) p.peak_r0 = getenv("QATTN_PEAK_R0") ? (float)atof(getenv("QATTN_PEAK_R0")) : e.peak_r0;   // (read per call: tools/ab.py variants)
-    if (a.precision == QATTN_PRECISION_AUTO && getenv("QATTN_PEAK_NEFF")) p.peak_neff = (float)atof(getenv("QATTN_PEAK_NEFF"));
-    if (getenv("QATTN_MAX_RESCUE")) p.max_rescue = atoi(getenv("QATTN_MAX_RESCUE"));
-    if (getenv("QATTN_MAX_RESCUE_ROWS")) p.max_rescue_rows = atoi(getenv("QATTN_MAX_RESCUE_ROWS"));
-    if (getenv("QATTN_PERSISTENT")) p.persistent = atoi(getenv("QATTN_PERSISTENT"));
-    if (getenv("QATTN_NO_SCHED")) p.sched = nullptr;   // static block order, rescues on the spot (round 2's behaviour)
-    if (getenv("QATTN_NO_RISKY")) p.risky_lo = p.risky_hi = 0;   // plain longest-first causal order
-    if (getenv("QATTN_DYN_MIN")) p.dyn_min_rounds = atoi(getenv("QATTN_DYN_MIN"));
-    if (getenv("QATTN_NO_FORECAST")) p.no_forecast = atoi(getenv("QATTN_NO_FORECAST"));
-    p.waves = !use_v2 ? kWaves : e.waves;
-    p.nqb = ceil_div(a.Sq, p.waves * kQPerWave);
-    p.lds_pad = e.lds; p.dbg = e.dbg; p.dbg_buf = nullptr;
-    static unsigned long long* dbg_dev = nullptr;
-    const long n_dbg_waves = (long)a.B * a.Hq * p.nqb * p.waves;
-    if (p.dbg & 16) {
-        if (!dbg_dev) (void)hipMalloc(&dbg_dev, sizeof(unsigned long long) * 2 * (1 << 20));
-        p.dbg_buf = dbg_dev;
-        (void)hipMemsetAsync(dbg_dev, 0, sizeof(unsigned long long) * 2 * n_dbg_waves, st);
-        (void)hipMemsetAsync(dbg_dev + 3 * (1 << 19), 0, sizeof(unsigned long long) * 256 * 32 * 5, st);
-    }
-    if (e.variant == 4) use_v2 = false;
-    if (e.causal_group > 0 && p.xcd_remap && ((a.B * a.Hq) >> 3) % e.causal_group == 0) p.causal_group = e.causal_group;
-#endif
+    const bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
     p.peak_z = (float)p.two_term_keys > kPeakR0 ? 0.5f + logf((float)p.two_term_keys / kPeakR0) : 0.0f;   // see predicted_r
     const bool prof = ds != nullptr;
     if (prof) (void)hipEventRecord(ds->prof[0], st);
-    int rc = QATTN_OK;
-    hipStream_t side = nullptr;
-    if (!v_is_16 && use_v2 && p.v16 != nullptr && p.q16 == nullptr) {
-        // fused step on the D = 128 kernel WITHOUT in-kernel Q quantisation (fp16 inputs): its early rows through a 16-bit-V launch of
-        // their own, the main launch skips those blocks (the bf16 fused step has the pass inside its kernel)
-        const int n_early = pv16_early_blocks(a.Sq, a.Skv, a.is_causal, p.two_term_keys);
-        if (n_early > 0) {
-            if (n_early < p.nqb) side = side_stream_fork(st);   // (beside the main launch: disjoint rows, see launch_v4_full_d)
-            rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.out_fmt, a.is_causal, a.scale_mode, side ? side : st, n_early);
-            p.skip_early = 1;
-        }
-    }
-    if (rc != QATTN_OK) { /* fall through to the error return below */ }
-    else if (v_is_16) rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
+    // (the fused step on the D = 128 kernel always quantises Q in the kernel -- q_fusion_ok -- and carries its 16-bit-V pass inside; the
+    // templated kernel's fused calls fork the launch of their early rows onto the side stream in launch_v4_full_d)
+    int rc;
+    if (v_is_16) rc = launch_attn_pv16(p, a.D, a.qk_fmt, a.v_fmt, a.is_causal, a.scale_mode, st);
     else if (use_v2) rc = launch_attn_v2(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
     else rc = launch_attn_v4_full(p, a.D, a.qk_fmt, a.is_causal, a.scale_mode, st);
-    if (side) {
-        const int rj = side_stream_join(st, side);
-        if (rc == QATTN_OK) rc = rj;
-    }
     if (prof) { (void)hipEventRecord(ds->prof[1], st); ds->recorded = true; }
     if (rc != QATTN_OK) return rc;
-#ifdef QATTN_DEV
-    if ((p.dbg & 16) && p.dbg_buf) {  // diagnostic path only: synchronises and prints per-wave sweep statistics
-        static int printed = 0;
-        (void)hipStreamSynchronize(st);
-        if (p.dbg & 64) {
-            const long rows = (long)a.B * a.Hq * a.Sq;
-            std::vector<float> r(rows * 4);
-            (void)hipMemcpy(r.data(), (const char*)p.dbg_buf + sizeof(unsigned long long) * (1 << 19), sizeof(float) * 4 * rows, hipMemcpyDeviceToHost);
-            std::vector<double> R;
-            for (long i = 0; i < rows; i++) { const float* d = &r[i * 4]; R.push_back(d[0] * exp2(-(5.0 + (d[1] - d[2]) * d[3]))); }
-            long n24 = 0; int shown = 0;
-            for (long i = 0; i < rows; i++) if (R[i] < 24.0) {
-                n24++;
-                if (shown++ < 6) fprintf(stderr, "[qattn dbg]   row %ld (head %ld, q %ld): R %.2f l %.1f delta %.3f\n", i, i / a.Sq, i % a.Sq, R[i], r[i * 4], (r[i * 4 + 1] - r[i * 4 + 2]) * r[i * 4 + 3]);
-            }
-            fprintf(stderr, "[qattn dbg] rows with R < 24: %ld of %ld = %.2e\n", n24, rows, (double)n24 / rows);
-            std::vector<double> Rs = R; std::sort(Rs.begin(), Rs.end());
-            fprintf(stderr, "[qattn dbg] R: min %.2f p1 %.2f med %.2f | row0: l %.1f m_true %.3f m_run %.3f c %.4e  row777: l %.1f m_true %.3f m_run %.3f\n", Rs[0], Rs[rows / 100], Rs[rows / 2],
-                    r[0], r[1], r[2], r[3], r[777 * 4], r[777 * 4 + 1], r[777 * 4 + 2]);
-        }
-        if (printed == 3 && (p.dbg & 8)) {   // block timeline (QATTN_V2_DBG=24): realtime stamps per wave, 10 ns ticks
-            std::vector<unsigned long long> tl(4 * n_dbg_waves);
-            (void)hipMemcpy(tl.data(), p.dbg_buf + (1 << 18), sizeof(unsigned long long) * 4 * n_dbg_waves, hipMemcpyDeviceToHost);
-            std::vector<double> pro, swp, epi, tot, skew;
-            unsigned long long first = ~0ull, last = 0;
-            for (long b = 0; b < n_dbg_waves / p.waves; b++) {
-                unsigned long long e0 = ~0ull, x1 = 0;
-                for (int w = 0; w < p.waves; w++) {
-                    const unsigned long long* t = &tl[4 * (b * p.waves + w)];
-                    if (!t[3]) continue;
-                    pro.push_back((t[1] - t[0]) * 0.01); swp.push_back((t[2] - t[1]) * 0.01); epi.push_back((t[3] - t[2]) * 0.01);
-                    e0 = std::min(e0, t[0]); x1 = std::max(x1, t[3]);
-                    first = std::min(first, t[0]); last = std::max(last, t[3]);
-                }
-                if (x1) tot.push_back((x1 - e0) * 0.01);
-            }
-            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
-            const double span = (last - first) * 0.01, blocks = (double)tot.size(), busy = med(tot) * blocks / 256.0;
-            fprintf(stderr, "[qattn dbg] timeline (us, medians over waves): prologue %.2f | sweep %.2f | epilogue+exit %.2f | block %.2f ; kernel span %.1f us, "
-                            "blocks %.0f -> %.1f blocks per CU x block = %.1f us (%.0f %% of the span)\n",
-                    med(pro), med(swp), med(epi), med(tot), span, blocks, blocks / 256.0, busy, 100.0 * busy / span);
-        }
-        if (printed == 3 && (p.dbg & 8) && use_v2) {   // work log of the persistent workgroups (10 ns ticks)
-            std::vector<unsigned long long> wl(256 * 32 * 5);
-            (void)hipMemcpy(wl.data(), p.dbg_buf + 3 * (1 << 19), sizeof(unsigned long long) * wl.size(), hipMemcpyDeviceToHost);
-            unsigned long long first = ~0ull, last = 0;
-            for (int g = 0; g < 256; g++) for (int r = 0; r < 32; r++) {
-                const unsigned long long* e = &wl[(g * 32 + r) * 5];
-                if (!e[0]) break;
-                first = std::min(first, e[1]); last = std::max(last, std::max(e[2], std::max(e[3], e[4])));
-            }
-            double blk = 0, resc = 0, draw = 0, lead = 0, idle = 0, max_idle = 0, max_resc = 0; int groups = 0, rounds = 0, nresc = 0;
-            std::vector<double> ends;
-            for (int g = 0; g < 256; g++) {
-                const unsigned long long* e0 = &wl[(g * 32) * 5];
-                if (!e0[0]) continue;
-                groups++;
-                lead += (e0[1] - first) * 0.01;
-                unsigned long long end = 0; double r_g = 0;
-                for (int r = 0; r < 32; r++) {
-                    const unsigned long long* e = &wl[(g * 32 + r) * 5];
-                    if (!e[0]) break;
-                    rounds++;
-                    blk += (e[2] - e[1]) * 0.01;
-                    const double rs = (e[3] - e[2]) * 0.01;
-                    if (rs > 0.5) { nresc++; }
-                    r_g += rs;
-                    draw += (e[4] - e[3]) * 0.01;
-                    end = std::max(end, e[4]);
-                }
-                resc += r_g; max_resc = std::max(max_resc, r_g);
-                const double id = (last - end) * 0.01;
-                idle += id; max_idle = std::max(max_idle, id); ends.push_back(id);
-            }
-            std::sort(ends.begin(), ends.end());
-            if (groups) {   // per XCD label (blockIdx.x & 7): mean time a workgroup spent in its blocks, mean finish time
-                char line[512]; int n = 0;
-                for (int x = 0; x < 8; x++) {
-                    double busy = 0, fin = 0; int cnt = 0;
-                    for (int g = x; g < 256; g += 8) {
-                        const unsigned long long* e0 = &wl[(g * 32) * 5];
-                        if (!e0[0]) continue;
-                        unsigned long long end = 0;
-                        for (int r = 0; r < 32; r++) { const unsigned long long* e = &wl[(g * 32 + r) * 5]; if (!e[0]) break; busy += (e[2] - e[1]) * 0.01; end = std::max(end, e[4]); }
-                        fin += (end - first) * 0.01; cnt++;
-                    }
-                    if (cnt) n += snprintf(line + n, sizeof(line) - n, " x%d %.0f/%.0f", x, busy / cnt, fin / cnt);
-                }
-                fprintf(stderr, "[qattn dbg] per XCD (mean us in blocks / mean finish):%s\n", line);
-            }
-            if (groups)
-                fprintf(stderr, "[qattn dbg] work log: span %.1f us, %d workgroups x %.2f rounds | per workgroup (mean us): start lag %.2f, blocks %.1f, "
-                                "rescues %.2f (max %.1f; %d rounds with one), draw + barrier %.2f, idle before the end %.2f (median %.2f, max %.1f)\n",
-                        (last - first) * 0.01, groups, (double)rounds / groups, lead / groups, blk / groups, resc / groups, max_resc, nresc, draw / groups,
-                        idle / groups, ends[ends.size() / 2], max_idle);
-        }
-        if (printed++ == 3) {
-            std::vector<unsigned long long> h(2 * n_dbg_waves);
-            (void)hipMemcpy(h.data(), p.dbg_buf, sizeof(unsigned long long) * 2 * n_dbg_waves, hipMemcpyDeviceToHost);
-            std::vector<double> cyc, clk;
-            for (long i = 0; i < n_dbg_waves; i++) if (h[2 * i + 1]) { cyc.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
-            if (!cyc.empty()) {
-                std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
-                const int iters = ceil_div(a.Skv, 64) + 2;
-                if (p.dbg & 32) {
-                    std::vector<unsigned long long> sg(64 * 8);
-                    (void)hipMemcpy(sg.data(), p.dbg_buf + 2 * (1 << 19), sizeof(unsigned long long) * 64 * 8, hipMemcpyDeviceToHost);
-                    double tot[6] = {0, 0, 0, 0, 0, 0};
-                    for (int w = 0; w < 64; w++) for (int i = 0; i < 6; i++) tot[i] += (double)sg[w * 8 + i] / 64.0;
-                    fprintf(stderr, "[qattn dbg] per-iteration segment cycles (mean of 64 waves): seg0 %.0f | seg1 %.0f | seg2 %.0f | seg3 %.0f | seg4 %.0f | seg5 %.0f\n",
-                            tot[0] / iters, tot[1] / iters, tot[2] / iters, tot[3] / iters, tot[4] / iters, tot[5] / iters);
-                }
-                if (p.xcd_remap && !a.is_causal) {   // per XCD (heads are XCD-contiguous): median sweep cycles and in-kernel clock of its waves
-                    char line[512]; int n = 0;
-                    const long per_xcd = n_dbg_waves / 8;
-                    for (int x = 0; x < 8; x++) {
-                        std::vector<double> cy, ck;
-                        for (long i = x * per_xcd; i < (x + 1) * per_xcd; i++) if (h[2 * i + 1]) { cy.push_back((double)h[2 * i]); ck.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
-                        if (cy.empty()) continue;
-                        std::sort(cy.begin(), cy.end()); std::sort(ck.begin(), ck.end());
-                        n += snprintf(line + n, sizeof(line) - n, " x%d %.0fk/%.3f", x, cy[cy.size() / 2] * 1e-3, ck[ck.size() / 2]);
-                    }
-                    fprintf(stderr, "[qattn dbg] per XCD (median sweep kcycles / clock GHz):%s\n", line);
-                }
-                fprintf(stderr, "[qattn dbg] waves=%zu sweep cycles median=%.0f (%.1f per iteration over %d) p10=%.0f p90=%.0f | in-kernel clock median %.3f GHz\n",
-                        cyc.size(), cyc[cyc.size() / 2], cyc[cyc.size() / 2] / iters, iters, cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10], clk[clk.size() / 2]);
-            }
-        }
-    }
-#endif
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
 
 // true when the attention kernel can quantise Q itself (hand-scheduled D = 128 kernel, head-wise scales, bf16 or -- since round 5 -- fp16
 // inputs, byte-exponential path): then the pre-pass skips Q's payload (one read and one write of Q less).
 bool q_fusion_ok(int D, int in_fmt, int scale_mode, int is_causal) {
-#ifdef QATTN_DEV
-    const DevEnv& e = dev_env();
-    if (e.variant != 2 || e.exact_exp || e.waves != 8 || e.no_q_fusion || getenv("QATTN_NO_Q_FUSION")) return false;   // (also per call: tools/ab.py variants)
-#endif
     return D == 128 && (in_fmt == QATTN_FMT_BF16 || in_fmt == QATTN_FMT_FP16) && scale_mode == QATTN_SCALE_HEAD && attn_v2_covers(D, is_causal, scale_mode);
 }
 
@@ -534,11 +335,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     // block-scaled V with head-wise scales wherever the kernel's PV products take the chunk's scale byte -- the hand-scheduled
     // D = 128 kernel in its fused-Q instantiation, the templated kernel (D = 64 / 256) -- and a head has at most kMomentSplits
     // chunks: V then needs no abs-max pass
-#ifdef QATTN_DEV
-    const bool v_block = fused_v_block(fuse_q, D, scale_mode, is_causal, Skv) && !getenv("QATTN_NO_VBLOCK") && dev_env().variant == 2;
-#else
     const bool v_block = fused_v_block(fuse_q, D, scale_mode, is_causal, Skv);
-#endif
     const float* ext_amax[3] = {amax_q, amax_k, amax_v};
     // the hand-out counters of the attention launch (D = 128 kernel) are cleared by the quantise pass on its way: a launch of
     // its own for 32 bytes sat between the two kernels for ~5 us

@@ -20,7 +20,7 @@ constexpr int kTwoTermKeys = 1024;           // query blocks that see fewer keys
 constexpr float kPeakR0 = 24.0f;
 // ... and when its effective key count N_eff = l^2 / sum P'^2 ends below this.  R bounds the LARGEST weight; K similar weights
 // that carry a row have R ~ K and a one-term error ~ eps_rms |v - O| / sqrt(K): 0.026 at K = 40, 0.017 at K = 100, 0.0125 at
-// K = 160, 0.010 at K = 256 (tools/sim_heavy.py; 2^-6 = 0.0156).  N(0,1) rows sit at n / e: 1500 at n = 4096, 390 at 1024,
+// K = 160, 0.010 at K = 256 (tools/models/sim_heavy.py; 2^-6 = 0.0156).  N(0,1) rows sit at n / e: 1500 at n = 4096, 390 at 1024,
 // where a row with R >= 24 is never below 192 (3e-4 of the rows at n = 1024).
 constexpr float kPeakNeff = 192.0f;
 // the e4m3 byte of P' read as e5m2 is 0.444 .. 0.5 of P'^2 over the eight mantissa values (mean 0.480); the MFMA that sums
@@ -105,7 +105,6 @@ struct AttnParams {
     int risky_lo, risky_hi;   // causal, AUTO: query blocks [lo, hi) of a head go FIRST (map_block); lo = hi: plain longest-first
     int tail_lo;              // causal, XCD-aware hand-out: the query blocks qb < tail_lo of ALL of an XCD's heads are handed out after everything else (map_block); 0: each group's own
     float sm_log2e;  // sm_scale * log2(e)
-    int exact_exp;   // 1: v_exp_f32 + RNE fp8 conversion everywhere (no byte-exponential fast path)
     int precision;   // QATTN_PRECISION_*
     int two_term_keys;  // kTwoTermKeys (a development switch can change it)
     int n_two;       // leading query blocks per head that start in two-term mode (set by the launcher)
@@ -123,7 +122,6 @@ struct AttnParams {
     // block from per-XCD counters (SchedState below).
     struct SchedState* sched;
     int sched_nq;                // block counters in use: 8 (one per XCD label blockIdx.x & 7) with xcd_remap, else 1
-    int no_forecast;             // dev switch
     const unsigned* vexp;        // fused step with a block-scaled V (else nullptr): E8M0 byte of every 64-key V chunk, [B*Hkv][ssq_stride]
     int max_rescue_rows;         // D = 128 kernel: more peaked ROWS than this in a 256-row block: the block is redone in two-term mode (fewer: gathered and rescued)
     int max_rescue;              // more peaked 32-row groups than this in a 256-row block: the block is redone in two-term mode   // > 0: one-term blocks with a row of R < peak_r0 are repeated in two-term mode (QATTN_PRECISION_AUTO)
@@ -133,7 +131,6 @@ struct AttnParams {
     // The ORIGINAL 16-bit V, row-major [B,Hkv,Skv,D] (else nullptr): what pv16_block_pass (qattn_pv16.h) attends -- every block of a
     // call with v_fmt = QATTN_FMT_BF16 / _FP16, and in the fused step the blocks that see fewer than two_term_keys keys (bf16)
     const unsigned char* v16;
-    int skip_early;                // D = 128 kernel: the blocks that see fewer than two_term_keys keys were attended by a 16-bit-V launch of their own (launch_attn_pv16): nothing to do for them here
     const unsigned char* q16;      // fused step: the 16-bit (bf16) Q tensor, quantised row by row in the kernel prologue (else nullptr)
     const unsigned* q_amax_part;   // fused step: abs-max words (fp32 bits) of every q head, [B*Hq][amax_stride], amax_n valid per head:
     int amax_n, amax_stride;       //   the abs-max pass's per-block words, or ONE caller-supplied word per head (producer hand-off)
@@ -146,12 +143,6 @@ struct AttnParams {
     // rows, two-term blocks of the templated kernel) or QATTN_PATH_V16 (16-bit P on the caller's 16-bit V: early blocks, blocks on the
     // 16-bit-V pass, severely peaked rescued rows).  The one-term sweeps never touch it.
     unsigned char* path;
-#ifdef QATTN_DEV
-    int waves;       // waves per workgroup of the v2 kernel (8 or 4): nqb is computed for waves*32 rows
-    int lds_pad;     // force this dynamic-LDS size (occupancy experiments), 0 = natural
-    unsigned long long* dbg_buf;  // per-wave {cycles, realtime ticks} of the KV sweep when dbg & 16
-    int dbg;         // 16 = stamp per-wave sweep cycles into dbg_buf
-#endif
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -214,7 +205,7 @@ __device__ inline int sched_next_block(SchedState* s, int nq, int x, int bpq, in
 //     no later rescale touched the row (m_run == m_true from then on), so its contribution carries no rounding error at
 //     all.  The row is then judged by its REST: with the top key taken out of both sums, l_r^2 / l2_r >= peak_r0^2 says that
 //     no other weight exceeds 1 / peak_r0 -- the same guarantee the R test gives an ordinary row.  On N(0,1) data nearly
-//     every row with R < 24 is one outlier key of exactly this kind (tools/sim_exact_top.py: 100 % at n = 4096, 77 % at 2048).
+//     every row with R < 24 is one outlier key of exactly this kind (tools/models/sim_exact_top.py: 100 % at n = 4096, 77 % at 2048).
 template <bool BYTE, bool NEFF>
 __device__ __forceinline__ bool row_is_peaked(const AttnParams& p, float l, float l2, float r_inv_pmax, bool top_is_reference, float nkeys) {
     static_assert(kPShift == 5.0f && kPShiftByte == 5.0f, "p_top below is 2^shift");
@@ -244,7 +235,7 @@ __device__ __forceinline__ bool row_is_peaked(const AttnParams& p, float l, floa
         // to zero -- however flat they are among themselves, and the sums above, made of the crushed bytes, cannot show it.  The R
         // test used to imply a floor (l >= 24 x 32 spread over n keys); a row excused from it by its exact top key has none,
         // found by tools/fuzz_parity.py on rows with one key 8 .. 10 nats above the rest (errors of 0.1 .. 0.3).  Model
-        // (tools/sim_crushed_rest.py): mean rest P' >= 0.05 keeps the one-term error below 0.012, < 0.04 does not.
+        // (tools/models/sim_crushed_rest.py): mean rest P' >= 0.05 keeps the one-term error below 0.012, < 0.04 does not.
         peaked = peaked || l_r < kCrushMean * nkeys;
     }
     return peaked;
@@ -543,7 +534,8 @@ constexpr int rescue_slot_bytes() { return ((D / 32) * 16 + 2) * 64 * 4; }   // 
 // The 32 rows are ANY rows of one head, one per lane pair (lanes l and l + 32): `row` (per lane; c and qfrag belong to it), of which
 // the lanes with `store` set are written; row_lo / row_hi (wave-uniform) bound the rows for the causal chunk count and the mask test.
 // The D = 128 kernel passes the flagged rows of a 256-row block, gathered from all its waves (rescue_pass); the wrapper below is the
-// contiguous group r0 .. r0 + 31 of the templated kernel's rescue launch.
+// contiguous group r0 .. r0 + 31 of the templated kernel's rescue launch.  (The rows' QATTN_PATH_TWO_TERM codes are written by the CALLERS
+// once this function's registers are dead: inside it the store cost the D = 256 rescue kernel a spilled register.)
 template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool QLDS = false, bool VSCALE = false, typename QFrag>
 __device__ __forceinline__ void rescue_rows_at(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                                int row, bool store, int row_lo, int row_hi, int wave, int lane, long bh, long kv_head, float c,
@@ -703,7 +695,6 @@ __device__ __forceinline__ void rescue_rows_at(const AttnParams& p, unsigned cha
         store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + row, hh, store && row < p.Sq);
         if (p.lse && hh == 0 && store && row < p.Sq)
             p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
-        if (p.path && hh == 0 && store && row < p.Sq) p.path[bh * p.Sq + row] = (unsigned char)QATTN_PATH_TWO_TERM;
     }
 }
 

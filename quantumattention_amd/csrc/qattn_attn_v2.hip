@@ -57,26 +57,6 @@ constexpr int v2_words_offset() { return (Q16 && NW == 8) ? kLdsAll - 4096 : 5 *
 constexpr int kSyncEvery = 2;                   // waves synchronise every kSyncEvery 64-key iterations
 constexpr int kStagesV2 = 2 * kSyncEvery + 1;   // ring slots: G live + G being filled + the previous V stage
 
-#ifdef QATTN_DEV
-// (dev library, 4-wave experiments) LDS-DMA copy of one stage image [K chunk | V chunk] = 2*64*D bytes, linear: every
-// wave-instruction moves 1 KiB (64 lanes x 16 B); wave w owns pieces r*(NW*1024) + w*1024, r < ROUNDS.
-template <int D, int NW>
-__device__ __forceinline__ void stage_dma(const unsigned char* ksrc, const unsigned char* vsrc, unsigned char* lds_stage,
-                                          int wave, int lane) {
-    constexpr int CH = 64 * D, ROUNDS = 2 * 64 * D / (NW * 64 * 16);
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const int o = r * (NW * 1024) + (wave << 10);
-        const unsigned char* ubase = o < CH ? ksrc + o : vsrc + (o - CH);  // wave-uniform: make it provably so (saddr form)
-        const unsigned long long ub = (unsigned long long)ubase;
-        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)ub), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
-        const unsigned char* src = (const unsigned char*)(((unsigned long long)hi32 << 32) | lo32) + (lane << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_stage + o), 16, 0, 0);
-    }
-}
-#endif
-
 template <int D, bool TWO, bool BYTE>
 struct WaveState {
     static constexpr int MB = D / 32;
@@ -96,7 +76,7 @@ struct WaveState {
     // NEFF (one-term passes under QATTN_PRECISION_AUTO): row sums of P'^2 for the effective key count l^2 / sum P'^2 (DESIGN.md
     // section 4.5).  BYTE: one more row-sum MFMA per chunk on the SAME P bytes with the B format switched to e5m2 -- the exponent
     // field of an e4m3 byte weighs twice as much when read as e5m2, so the byte of 2^x reads as 0.444 .. 0.5 of 2^(2x)
-    // (kNeffByteRatio; tools/sim_heavy.py).  Exact mode: fp32 fmas beside the row sum (l2_run).
+    // (kNeffByteRatio; tools/models/sim_heavy.py).  Exact mode: fp32 fmas beside the row sum (l2_run).
     v4f lsq;
     float l2_run;
     v8i qreg[2];   // QREG kernels: the wave's Q^T fragments (both k-steps) held in registers instead of re-read from LDS
@@ -106,10 +86,6 @@ struct WaveState {
     float mcv;     // the additive constant of the exponent / byte formula for the current m_run (full_step: mc)
     float lim;     // m_run + thr / c: a row's chunk max above it means P' could overflow -> fix-up
     int vsx;       // block-scaled V: scale word (vscale_word) of the V chunk the current iteration's PV products read
-#ifdef QATTN_DEV
-    unsigned long long seg[6];  // diagnostic builds (ABL & 16): cycles per segment of the iteration
-    unsigned long long tlast;
-#endif
 };
 
 template <int QK_FMT, int D>
@@ -176,25 +152,14 @@ __device__ __forceinline__ void exp_group(const v16f& sx, int j, float c, float 
 // 2^e*(1+m/8), so byte ~= 8*x + 56 (Schraudolph's exponent trick at 3 mantissa bits): one fma + one saturating
 // round-to-nearest v_cvt_pk_u8_f32 per score (profiles/r01_cvt_u8_probe.log) instead of fma + v_exp_f32 + half a
 // v_cvt_pk_fp8_f32 (~17 issue cycles -> ~6).  c8 = 8c, off8 = 8*(shift - m*c) + 56 + kByteBias.  -inf -> 0.
-template <bool PKFMA>
-__device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, float off8, v8i& pv, int w, int seed) {
-    // 5 VALU per 4 scores: two v_pk_fma_f32 (c8/off8 carry a factor 1/65535), two v_cvt_pknorm_u16_f32 (round to nearest,
-    // clamps to [0, 65535], -inf/NaN -> 0: profiles/r01_pknorm_probe.log) and one v_perm_b32 gathering the four low bytes
-    typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, float off8, v8i& pv, int w) {
+    // 7 VALU per 4 scores: four v_fma_f32 (c8 / off8 carry a factor 1/65535), two v_cvt_pknorm_u16_f32 (round to nearest, clamps to
+    // [0, 65535], -inf/NaN -> 0: profiles/r01_pknorm_probe.log) and one v_perm_b32 gathering the four low bytes.  (Two v_pk_fma_f32 instead
+    // of the four v_fma_f32 were measured in round 1: packed-fp32 VALU stalls behind a running MFMA, +25 % cycles -- profiles/r01_ablation.md.)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    (void)seed;
-    // op_sel_hi:[1,0,0]: both halves take the LOW register of the c8 / off8 pairs, whose high halves stay unset
-    // (the compiler scalarises a <2 x float> fma with splat operands into two v_fma_f32, hence the asm)
-    const f2 cc = {c8, __builtin_nondeterministic_value(c8)}, oo = {off8, __builtin_nondeterministic_value(off8)};
-    f2 a, b2;
-    if (PKFMA) {
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(a) : "v"(f2{sx[4 * j + 0], sx[4 * j + 1]}), "v"(cc), "v"(oo));
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(b2) : "v"(f2{sx[4 * j + 2], sx[4 * j + 3]}), "v"(cc), "v"(oo));
-    } else {
-        a = f2{__builtin_fmaf(sx[4 * j + 0], c8, off8), __builtin_fmaf(sx[4 * j + 1], c8, off8)};
-        b2 = f2{__builtin_fmaf(sx[4 * j + 2], c8, off8), __builtin_fmaf(sx[4 * j + 3], c8, off8)};
-    }
-    const us2 qa = __builtin_amdgcn_cvt_pknorm_u16(a[0], a[1]), qb = __builtin_amdgcn_cvt_pknorm_u16(b2[0], b2[1]);
+    const float a0 = __builtin_fmaf(sx[4 * j + 0], c8, off8), a1 = __builtin_fmaf(sx[4 * j + 1], c8, off8);
+    const float b0 = __builtin_fmaf(sx[4 * j + 2], c8, off8), b1 = __builtin_fmaf(sx[4 * j + 3], c8, off8);
+    const us2 qa = __builtin_amdgcn_cvt_pknorm_u16(a0, a1), qb = __builtin_amdgcn_cvt_pknorm_u16(b0, b1);
     unsigned ua, ub;
     __builtin_memcpy(&ua, &qa, 4);
     __builtin_memcpy(&ub, &qb, 4);
@@ -203,36 +168,11 @@ __device__ __forceinline__ void byte_group(const v16f& sx, int j, float c8, floa
     pv[w] = (int)b;
 }
 
-__device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, float off8, v8i& pv, int w, int seed) {
-    unsigned b = (unsigned)seed;
-#pragma unroll
-    for (int i = 0; i < 4; i++) b = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(sx[4 * j + i], c8, off8), i, b);
-    asm volatile("" : "+v"(b));
-    pv[w] = (int)b;
-}
-
 
 #define QATTN_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef QATTN_DEV
-#define QATTN2_STAMP(I) do { } while (0)
-#else
-#define QATTN2_STAMP(I)                                                                                          \
-    do {                                                                                                        \
-        if (ABL & 16) {                                                                                         \
-            unsigned long long t_;                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-            st.seg[I] += t_ - st.tlast;                                                                         \
-            st.tlast = t_;                                                                                      \
-        }                                                                                                       \
-    } while (0)
-#endif
 #define QATTN_SM_GROUP(FIRST, SX, J, MC, W, SEED)                                   \
     do {                                                                            \
-        if (ABL & 4) break;                                                         \
-        if (BYTE && (ABL & 32)) byte_group_u8(SX, J, cx, MC, pc, W, SEED);           \
-        else if (BYTE) byte_group<false>(SX, J, cx, MC, pc, W, SEED);                \
+        if (BYTE) byte_group(SX, J, cx, MC, pc, W);                                 \
         else exp_group<TWO, FIRST, NEFF, !SUMM>(SX, J, cx, MC, acc, pc, pcl, W, SEED, acc2); \
     } while (0)
 
@@ -245,12 +185,11 @@ __device__ __forceinline__ void byte_group_u8(const v16f& sx, int j, float c8, f
 // bandwidth, are the scarce resource at two waves per SIMD).
 //   kbuf  : stage(t),   K part  (+ lane offset)      vprev : stage(t-1), V part = V(t-2)
 //   vnext : stage(t),   V part = V(t-1) (prefetch for the next iteration)
-template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, bool SUMM = false, typename Stage>
+template <int D, int QK_FMT, int V_FMT, int PAR, bool TWO, bool BYTE, int ABL = 0 /* 1024: the stamped measurement instantiation; else 0 */, bool QREG = false, bool VS = false, bool NEFF = false, bool SUMM = false, typename Stage>
 __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const unsigned char* kbuf, const unsigned char* vprev,
                                           const unsigned char* vnext, const unsigned char* qbuf, Stage&& stage, const unsigned* vx_next = nullptr) {
     static_assert(D == 128, "hand-placed slots are written for D = 128");
-    // ABL (timing-only ablations, results wrong): 4 = no softmax VALU, 8 = no LDS fragment reads (operands = a fixed register set)
-    auto LDSF = [&](const unsigned char* ptr) -> v8i { if (ABL & 8) return st.vpre[0]; return lds_read_frag(ptr); };
+    auto LDSF = [&](const unsigned char* ptr) -> v8i { return lds_read_frag(ptr); };
     constexpr int PL_R = TWO ? PAR : 0, PL_W = TWO ? (PAR ^ 1) : 0;
     v16f& sn0 = st.s[PAR][0];            // S(t)   tile 0 (keys  0..31 of chunk t)
     v16f& sn1 = st.s[PAR][1];            //        tile 1 (keys 32..63)
@@ -264,7 +203,7 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     const float c = st.c;
     // exact mode: p' = exp2(s*c + mc);  byte mode: byte = rne(s*c8 + mc)  (c8 = 8c, mc = 8*(shift - m*c) + 56 + bias)
     // (byte mode carries the 1/65535 of v_cvt_pknorm_u16_f32's [0,1] -> [0,65535] map in both constants)
-    constexpr float U16 = (ABL & 32) ? 1.0f : 1.0f / 65535.0f;
+    constexpr float U16 = 1.0f / 65535.0f;
     const float cx = BYTE ? (8.0f * U16) * c : c;
     const float mc = st.mcv;
     float acc[4], acc2[4];
@@ -313,7 +252,6 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     v8i kb = LDSF(kbuf + (2 << 11));
     QATTN_SM_GROUP(false, sc0, 2, mc, 2, pc[1]);
     QATTN_SLOT_FENCE();
-    QATTN2_STAMP(1);
     stage();  // K/V staging of a later chunk: after the PV slots are in flight, not between the barrier and the first MFMA
     // slot 4 (BYTE): row sum of the quantised P(t-2) on the matrix pipe: ones(32x64).P^T -> every row = sum over 64 keys
     if (BYTE || SUMM) st.lsum = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st.ones, pp, st.lsum, QATTN_FMT_E4M3, QATTN_FMT_E4M3, 0, 0, 0, 0);
@@ -358,7 +296,6 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     float ls = (BYTE || SUMM) ? 0.0f : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     float ls2 = (BYTE || !NEFF) ? 0.0f : (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]);
     QATTN_SLOT_FENCE();
-    QATTN2_STAMP(2);
     // rare fix-up: some row's max grew by more than the threshold (always on the first chunk: m_run = -1e30):
     // rescale everything accumulated so far (O and the row sum include chunk t-2) and redo this chunk's exponentials
     if (__builtin_expect(__any(mx > st.lim) != 0, 0)) {   // (mx - m_run) c > THR
@@ -391,7 +328,6 @@ __device__ __forceinline__ void full_step(WaveState<D, TWO, BYTE>& st, const uns
     }
     st.l_run += ls;
     if (NEFF) st.l2_run += ls2;
-    QATTN2_STAMP(3);
 }
 
 // One stage of the K/V ring by LDS-DMA (8-wave workgroups: one 1 KiB piece of K and one of V per wave): K at byte offset koff of
@@ -416,16 +352,12 @@ __device__ __forceinline__ void stage_dma8(const unsigned char* kg, const unsign
 // going to be repeated in two-term mode anyway: after two more chunks (the votes travel through the sweep's own barrier) all
 // waves drain the ring, stop and return true -- 3 of n chunks wasted instead of all of them.  Chunk 0 stands for the whole
 // key range here; where it does not, the R test at the end of the sweep is still the arbiter.
-// `prefetch` (NPF > 0: non-causal one-term passes): called once, two or three iterations before the sweep ends, it may request the NEXT
-// block's Q rows -- NPF LDS-DMA pieces per wave into a dump slot nobody reads, which leaves the rows in this XCD's L2 -- and says
-// whether it did; the sweep's remaining waits then leave those NPF youngest requests in flight (s_waitcnt vmcnt(NPF): the counter is in
-// order and no K/V stage is requested after this point of a non-causal sweep).
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, int NPF = 0, bool SUMM = false, typename LoadQ, typename Prefetch>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL = 0, bool QREG = false, bool VS = false, bool NEFF = false, bool SUMM = false, typename LoadQ>
 __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const AttnParams& p, unsigned char* smem,
                                          const unsigned char* kg, const unsigned char* vg, const unsigned char* qbuf, int n_wg,
                                          int n_w, int q0, int qrow, int wave, int lane, const float* skt, LoadQ&& load_q,
                                          bool forecast, unsigned* vote, const unsigned* vx,   // vx (VS): the V chunks' scale bytes in LDS
-                                         bool first_stages_issued, Prefetch&& prefetch) {   // first_stages_issued: the caller has requested stages 0 .. kSyncEvery - 1 already
+                                         bool first_stages_issued) {   // first_stages_issued: the caller has requested stages 0 .. kSyncEvery - 1 already
     constexpr int CH = 64 * D, STAGE = 2 * CH;
     const int hh = lane >> 5;
     const int T = n_wg + 2;  // iterations t = 0 .. n_wg+1 : QK(t), softmax(t-1), PV(t-2)
@@ -445,23 +377,17 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     // Stages are issued strictly in order, so the DMA source/destination advance incrementally (a handful of SALU per
     // stage instead of ~40 for the modulo / clamp / 64-bit address arithmetic of an indexed form): koff = byte offset of
     // K(min(t, n-1)) within the head, voff = that of V(min(max(t-1, 0), n-1)) = the previous stage's koff.
-    static_assert(2 * 64 * D / (NW * 1024) == 2 || NW != 8, "one K and one V DMA per wave and stage");
+    static_assert(NW == 8 && 2 * 64 * D / (NW * 1024) == 2, "one K and one V DMA per wave and stage");
     const unsigned char* kg_w = kg + (wave << 10);
     const unsigned char* vg_w = vg + (wave << 10);
     const unsigned koff_max = (unsigned)(p.nchunks - 1) * CH;
     unsigned koff = 0, voff = 0, lds_next = 0;
     const unsigned lane16 = (unsigned)lane << 4;
     auto dma_next = [&]() __attribute__((always_inline)) {
-        if (NW == 8) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (koff + lane16)),
-                                             (__attribute__((address_space(3))) void*)(smem + lds_next + (wave << 10)), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (voff + lane16)),
-                                             (__attribute__((address_space(3))) void*)(smem + lds_next + CH + (wave << 10)), 16, 0, 0);
-        } else {
-#ifdef QATTN_DEV
-            stage_dma<D, NW>(kg + koff, vg + voff, smem + lds_next, wave, lane);
-#endif
-        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg_w + (koff + lane16)),
+                                         (__attribute__((address_space(3))) void*)(smem + lds_next + (wave << 10)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg_w + (voff + lane16)),
+                                         (__attribute__((address_space(3))) void*)(smem + lds_next + CH + (wave << 10)), 16, 0, 0);
         voff = koff;
         koff = min(koff + (unsigned)CH, koff_max);
         lds_next = lds_next + STAGE == kStagesV2 * STAGE ? 0u : lds_next + STAGE;
@@ -483,35 +409,14 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         (void)in_step;
         if (t % kSyncEvery == 0) {
             wait_vmcnt<0>();  // this wave's pieces of stages t .. t+G-1 have landed
-            QATTN2_STAMP(4);
-            if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
-            QATTN2_STAMP(5);
-            if (!(ABL & 1)) {
+            __builtin_amdgcn_s_barrier();
 #pragma unroll
-                for (int g = 0; g < kSyncEvery; g++)
-                    if (t + kSyncEvery + g < T) dma_for(t + kSyncEvery + g);
-            }
+            for (int g = 0; g < kSyncEvery; g++)
+                if (t + kSyncEvery + g < T) dma_for(t + kSyncEvery + g);
         } else {
             asm volatile("s_nop 0" ::: "memory");  // keeps the iterations of a group separate scheduling regions
         }
         return smem + slot_cur + frag_lane_off;
-    };
-    // the same for the last iterations of a sweep whose caller may have requests of its own in flight (see `prefetch` above)
-    static_assert(NPF == 0 || !CAUSAL, "a causal sweep requests K/V stages to its end");
-    bool pf_issued = false;
-    auto sync_tail = [&](int t) __attribute__((always_inline)) -> const unsigned char* {
-        if constexpr (NPF == 0) return sync_iter(t, true);
-        else {
-            if (t % kSyncEvery == 0) {
-                if (pf_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
-                else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                // (t + kSyncEvery >= T here: nothing left to request)
-            } else {
-                asm volatile("s_nop 0" ::: "memory");
-            }
-            return smem + slot_cur + frag_lane_off;
-        }
     };
     auto advance = [&]() __attribute__((always_inline)) {  // slot_cur / slot_prev: LDS offsets of stage(t) / stage(t-1), advanced once per iteration
         slot_prev = slot_cur;
@@ -528,10 +433,9 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         const unsigned char* kbuf;
-        if constexpr (NPF > 0 && RAGGED) kbuf = sync_tail(t); else kbuf = sync_iter(t, true);   // (non-causal: RAGGED marks the sweep's last iterations)
+        kbuf = sync_iter(t, true);
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         advance();
-        QATTN2_STAMP(0);
         // (RAGGED = false, head-wise: the chunk lies inside the key range AND below the wave's causal diagonal -- nothing to prepare)
         if constexpr (RAGGED || TOKEN) prep_scores<CAUSAL, TOKEN, RAGGED>(st.s[PAR ^ 1][0], st.s[PAR ^ 1][1], p, (t - 1) * 64, q0, qrow, hh, skt);
         auto stage = [&]() { do_stage(t); };
@@ -548,10 +452,6 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     // instead of 276 instructions per two iterations, 5.1 scalar instructions per MFMA at C3 (VERDICT r3 Weak-5).
     using Inner = std::integral_constant<bool, false>;
     using Last = std::integral_constant<bool, true>;
-#ifdef QATTN_DEV
-    for (int i = 0; i < 6; i++) st.seg[i] = 0;
-    st.tlast = __builtin_amdgcn_s_memtime();
-#endif
     if (BYTE || SUMM) {
         {   // A of the row-sum MFMA: lane = row (l & 15) + 16 * k-group; rows 0 / 1 are 1.0 (e4m3 0x38) on even / odd k-groups
             const int row = lane & 15, kg = lane >> 4;
@@ -573,9 +473,9 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     // branch: 64 multiplications of an all-zero O^T by alpha = 0 and a second pass over the chunk's exponentials, with every wave of
     // the workgroup in it at once (nothing on the matrix pipe meanwhile) -- once per block.  Setting m_run / mcv / lim here with the
     // branch's own expressions gives the same bits: the first step's optimistic exponentials ARE the branch's recomputed ones.
-    if constexpr (!TOKEN && (ABL & 4) == 0) {   // (token-wise key scales are applied by prep_scores, which must then run once per chunk)
+    if constexpr (!TOKEN) {   // (token-wise key scales are applied by prep_scores, which must then run once per chunk)
         constexpr float SHIFT = BYTE ? kPShiftByte : kPShift, THR = BYTE ? kRescaleThrByte : kRescaleThr;
-        constexpr float U16 = (ABL & 32) ? 1.0f : 1.0f / 65535.0f;
+        constexpr float U16 = 1.0f / 65535.0f;
         prep_scores<CAUSAL, TOKEN, true>(st.s[0][0], st.s[0][1], p, 0, q0, qrow, hh, skt);   // (idempotent: the first step masks chunk 0 again)
         float mx0 = max32_after_mfma(st.s[0][0], st.s[0][1]);
         const auto sw0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx0), __float_as_uint(mx0), false, false);
@@ -587,10 +487,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // t = 1 .. n_w: full pipelined steps, two per trip (parity 1 then 0), no per-iteration branching
     int t = 1;
-    constexpr bool FORECAST = !TOKEN && !TWO && BYTE && (ABL & ~(512 | 1024)) == 0;   // (run-time: only passes that check their rows ask for it)
-#ifdef QATTN_DEV
-    if (p.no_forecast) forecast = false;   // QATTN_NO_FORECAST=1: A/B switch
-#endif
+    constexpr bool FORECAST = !TOKEN && !TWO && BYTE;   // (run-time: only passes that check their rows ask for it)
     // every wave of the workgroup runs the first two iterations (causal: wave 0 has the fewest chunks) and the sweep is long enough to matter
     const int n_w0 = CAUSAL ? min(n_wg, (q0 - wave * kQPerWave + kQPerWave - 1) / 64 + 1) : n_w;
     forecast = FORECAST && forecast && n_w0 >= 3 && n_wg >= 16;
@@ -634,7 +531,6 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
             }
         }
     }
-    if constexpr (NPF > 0) pf_issued = prefetch();   // (every K/V stage of the sweep has been requested by now)
     for (; t + 1 <= n_w; t += 2) {  // at most one trip
         full(P1{}, t, Last{});
         full(P0{}, t + 1, Last{});
@@ -645,7 +541,7 @@ __device__ __forceinline__ bool kv_sweep(WaveState<D, TWO, BYTE>& st, const Attn
     }
     // t = n_w + 1: the last chunk's PV (V(t-2) lives in stage(t-1); its row blocks 0,1 are already in vpre)
     {
-        if constexpr (NPF > 0) (void)sync_tail(t); else (void)sync_iter(t);
+        (void)sync_iter(t);
         const unsigned char* vprev = smem + slot_prev + CH + frag_lane_off;
         const v8i fc = lds_read_frag(vprev + (2 << 11)), fd = lds_read_frag(vprev + (3 << 11));
         // (VS: st.vsx already holds the scale of V(t - 2) = V(n_w - 1), requested by the last full step)
@@ -702,11 +598,11 @@ __device__ __forceinline__ void draw_finish(const AttnParams& p, volatile unsign
 // caller repeats the block in two-term mode -- or the bit mask of the (at most max_rescue) waves whose 32-row groups
 // rescue_pass then recomputes; the other waves' rows (and the optional LSE) are stored.  0: everything is stored.
 constexpr int kPassRedo = 1 << 30;
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, bool NEFF = false, int NPF = 0, bool SUMM = false, typename LoadQ, typename Prefetch>
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TWO, bool BYTE, int ABL, bool QREG, bool VS = false, bool NEFF = false, bool SUMM = false, typename LoadQ>
 __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
                                              int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q,
-                                             const unsigned* vx, bool first_stages_issued, volatile unsigned* mail, Prefetch&& prefetch) {
+                                             const unsigned* vx, bool first_stages_issued, volatile unsigned* mail) {
     constexpr int MB = D / 32;
     const int hh = lane >> 5;
     WaveState<D, TWO, BYTE> st;
@@ -724,10 +620,6 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     st.mcv = 0.0f;       // (the first chunk always takes the fix-up branch, which sets both)
     st.lim = -1.0e30f;
     st.vsx = kScaleWordOne;
-#ifdef QATTN_DEV
-    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
-    if (p.dbg & 16) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
     // ABL & 1024: the MEASUREMENT instantiation (qattn_fp8_quant_attention_forward_stamped): every wave brackets its KV sweep with
     // the shader-cycle counter and the 100 MHz real-time counter; their ratio is the clock the chip held INSIDE the kernel
     // (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to a buffer of their own, nothing is computed from them; the
@@ -746,8 +638,8 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             st.qreg[1] = lds_read_frag(qbuf + (1 << 11));
         }
     };
-    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF, NPF, SUMM>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
-                                                                                     !TWO && check_peaked, vote, vx, first_stages_issued, prefetch))
+    if (kv_sweep<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, VS, NEFF, SUMM>(st, p, smem, kg, vg, qbuf, n_wg, n_w, q0, qrow, wave, lane, skt, load_q_frags,
+                                                                                !TWO && check_peaked, vote, vx, first_stages_issued))
     {   // forecast: the block is peaked, nothing was stored (its successor is drawn here: the repeated pass draws nothing)
         const int t_ = (wave << 6) | lane;
         draw_finish(p, mail, t_, draw_issue(p, mail, t_));
@@ -761,22 +653,6 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
             p.stamp_buf[2 * wid + 1] = r1 - stamp_r0;
         }
     }
-#ifdef QATTN_DEV
-    if (p.dbg & 16) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            const long wid = (bh * p.nqb + (q0 - wave * kQPerWave) / (NW * kQPerWave)) * NW + wave;
-            p.dbg_buf[2 * wid] = t1 - dbg_t0;
-            p.dbg_buf[2 * wid + 1] = r1 - dbg_r0;
-            p.dbg_buf[(1 << 18) + 4 * wid + 1] = dbg_r0;   // timeline: sweep start / end (100 MHz ticks)
-            p.dbg_buf[(1 << 18) + 4 * wid + 2] = r1;
-            if ((ABL & 16) && wid < 64) {
-                unsigned long long* segout = p.dbg_buf + 2 * (1 << 19) + wid * 8;
-                for (int i = 0; i < 6; i++) segout[i] = st.seg[i];
-            }
-        }
-    }
-#endif
     const float m_run = st.m_run, l_run = st.l_run;
     v16f (&o)[MB] = st.o;
     const int tid_draw = (wave << 6) | lane;
@@ -805,24 +681,13 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
         // R = l' / p'_max with p'_max = 2^(shift + (m_true - m_run) c): the inverse of the row's largest softmax weight
         const float r_inv_pmax = __builtin_amdgcn_exp2f(-(SHIFT + (st.m_true - m_run) * c));
         const bool peaked = qrow < p.Sq && row_is_peaked<BYTE, NEFF>(p, l_tot, l2_tot, r_inv_pmax, st.m_true == m_run, (float)(CAUSAL ? min(qrow + 1, p.Skv) : p.Skv));
-#ifdef QATTN_DEV
-        if ((p.dbg & 64) && p.dbg_buf && qrow < p.Sq && hh == 0) {
-            float* d = reinterpret_cast<float*>(p.dbg_buf + (1 << 19)) + (bh * p.Sq + qrow) * 4;
-            d[0] = l_tot; d[1] = st.m_true; d[2] = m_run; d[3] = c;
-        }
-#endif
         // per-wave masks of the peaked ROWS (both half-waves reach the same verdict: bit r = the wave's row r) -> after the barrier every
         // wave knows how many rows of the block need help.  Few: they are gathered across the waves into dense 32-row groups and
         // recomputed (rescue_pass); many: the block repeats in two-term mode.  Rows, not 32-row groups, are the unit: on data with a
         // score spread of 1.2 .. 1.6 about 1 .. 6 % of the rows end peaked -- a handful per block, but spread over most of its eight
         // groups, which used to send nearly every such block into the two-term repeat.
-#ifdef QATTN_DEV
-        const unsigned mine = p.peak_r0 > 1.0e6f ? (wave == 0 ? 1u : 0u) : (unsigned)__ballot(peaked);   // QATTN_PEAK_R0=1e7: rescue row 0 of every block (timing)
-        const bool keep = p.peak_r0 > 1.0e6f ? !(wave == 0 && (lane & 31) == 0) : !peaked;
-#else
         const unsigned mine = (unsigned)__ballot(peaked);   // (low word: lanes 0 .. 31)
         const bool keep = !peaked;
-#endif
         // every row that is final is stored right away (under the other waves' last iterations, as in the unchecked kernel); the
         // peaked ones are left to whoever recomputes them -- a second store to the same address from another wave is not ordered
         // behind this one
@@ -999,42 +864,13 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
         }
     };
     // head-wise one-term byte-exponential kernels have 16 registers to spare and hold the Q^T fragments in them
-    constexpr bool QREG = BYTE && !TWO && !TOKEN && !(ABL & 128);
-    // MEASURED AND LEFT OFF (round 4, QATTN_QPREFETCH = 0; profiles/r04/ab_c2_q_prefetch_variants.log: fused step auto +0.3 %, fast 0 %; separate
-    // call auto +0.3 %, fast -1.7 %; non-temporal form +0.5 %: 64 KiB of once-read bf16 rows per block and CU compete with the two live heads'
-    // K / V for the XCD's 4 MiB L2).  What it does when built in:
-    // Static non-causal launches know their next block (bid + grid): near the end of the sweep every wave asks for ITS 32 rows of that
-    // block's Q -- 8 KiB of bf16 (fused step) or 4 KiB of fp8, read exactly once and therefore never in a cache -- by LDS-DMA into a 1 KiB
-    // dump slot behind the V scale words.  Nothing reads the slot; the point is that the rows then sit in this XCD's L2 when the next
-    // block's prologue asks for them in earnest: that request is the longest wait of a block's prologue (dev timeline: prologue 2.9 us
-    // of a 65 us block) and no register survives the block boundary for it (round 3's register prefetch: +25 registers, spills).
-#ifndef QATTN_QPREFETCH
-#define QATTN_QPREFETCH 0   // (a build knob for tools/ab.py variants: 0 = off, 1 = default cache policy, 2 = non-temporal)
-#endif
-    constexpr int NPF = (QATTN_QPREFETCH != 0 && !CAUSAL && !TWO && BYTE && !TOKEN && NW == 8 && ABL == 0) ? (Q16 ? 8 : 4) : 0;
-    auto prefetch_next = [&]() -> bool {
-        if constexpr (NPF == 0) return false;
-        else {
-            const int nb = bid + (int)gridDim.x;
-            if (p.sched != nullptr || nb >= p.total_blocks) return false;   // dynamic hand-out / last round (workgroup-uniform)
-            int head2, qb2;
-            map_block(p, nb, p.nqb, false, head2, qb2);
-            constexpr int RB = Q16 ? 2 * D : D;          // bytes per Q row
-            constexpr int RPP = 1024 / RB;               // rows per 1 KiB piece
-            const unsigned char* qsrc = Q16 ? p.q16 : p.q;
-            unsigned char* dump = smem + v2_words_offset<D, NW, Q16>() + 64 + 4 * kVxWords;
-#pragma unroll
-            for (int j = 0; j < NPF; j++) {
-                const int r = min(qb2 * QWG + wave * kQPerWave + j * RPP + lane / (RB / 16), p.Sq - 1);
-                const unsigned char* src = qsrc + ((long)head2 * p.Sq + r) * RB + (lane % (RB / 16)) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dump, 16, 0,
-                                                 QATTN_QPREFETCH == 2 ? 2 : 0);
-            }
-            return true;
-        }
-    };
-    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO && !(ABL & 512), NPF, SUMM && TWO && !BYTE>(   // (ABL 512: dev timing of the statistic's cost)
-        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst, mail, prefetch_next);
+    constexpr bool QREG = BYTE && !TWO && !TOKEN;
+    // (Measured and removed: prefetching the NEXT block's Q rows near the end of a static non-causal sweep -- LDS-DMA into a dump slot, to have
+    // them in this XCD's L2 when the next prologue asks: fused step auto +0.3 %, fast 0 %, non-temporal form +0.5 %; 64 KiB of once-read
+    // bf16 rows per block and CU compete with the two live heads' K / V for the XCD's 4 MiB L2.  profiles/r04/ab_c2_q_prefetch_variants.log;
+    // the code is in the history up to round 5.)
+    return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO, SUMM && TWO && !BYTE>(
+        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst, mail);
 }
 
 // The rescue of a block's flagged 32-row groups as a pass of its own, run by whichever workgroup took the queue item (or by the
@@ -1145,9 +981,11 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
                 done16 = true;
             }
         }
-        if (!done16)
+        if (!done16) {
             rescue_rows_at<D, NW, QK_FMT, V_FMT, CAUSAL, false, true, true>(p, smem, kg, vg, row, have, row_lo, row_hi, wave, lane, bh, kv_head, c, nullptr,
                                                                            [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); }, Q16 ? vx : nullptr);
+            if (p.path && wave == 0 && hh == 0 && have && qvalid) p.path[bh * p.Sq + row] = (unsigned char)QATTN_PATH_TWO_TERM;   // (fused entry's debug output)
+        }
     }
 }
 
@@ -1162,13 +1000,6 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
     // sequences -- runs the reference kernel's own P.V numerics, 16-bit P on the un-quantised V (qattn_pv16.h), instead of two-term fp8
     // P on the fp8 V: row 0 of a causal head IS V[0], and an fp8 V puts its rounding error (up to 2^-4 relative) straight into the output.
     // The same MFMA time as the two-term pass (16 bf16 products of 32 cycles for 8 fp8 products of 64), fewer VALU instructions.
-    if (p.skip_early) {   // (those blocks ran in a 16-bit-V launch of their own: fp16 inputs, launch_attn_pv16 in qattn_api.hip)
-        const int nkeys0 = CAUSAL ? min(p.Skv, qb * (NW * kQPerWave) + 1) : p.Skv;
-        if (nkeys0 < p.two_term_keys) {
-            draw_finish(p, mail, tid, draw_issue(p, mail, tid));
-            return 0u;
-        }
-    }
     // ... and so does (round 5) every block of the fused step that used to run two-term fp8 P: blocks predicted peaked, blocks that
     // repeat after a one-term sweep with too many flagged rows, every block under QATTN_PRECISION_ACCURATE (`pass16` below).  The same
     // MFMA time as the two-term pass, fewer vector instructions, and the rows that need the precision most no longer attend an fp8 V.
@@ -1177,7 +1008,7 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
 #ifndef QATTN_PV16_PIPELINED
 #define QATTN_PV16_PIPELINED 1   // (a build knob for tools/ab.py variants: 0 = the un-pipelined pass of round 4 everywhere)
 #endif
-        if constexpr (NW == 8) {   // (NW = 4: dev instantiations only, never the fused step)
+        if constexpr (NW == 8) {
             if constexpr (QATTN_PV16_PIPELINED != 0)
                 pv16p_block_pass<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, tid, bid, [&]() { return draw_issue(p, mail_, tid); },
                                                               [&](unsigned ticket) { draw_finish(p, mail_, tid, ticket); });
@@ -1220,19 +1051,6 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
         const bool start_two = predicted_r((float)nkeys, 1.0f, p.peak_z) < kPeakR0 || (wide && many_rows_peaked((float)nkeys, var));
         two = __builtin_amdgcn_readfirstlane(start_two ? 1 : 0) != 0;   // (every lane holds the same value)
     }
-#ifdef QATTN_DEV
-    const unsigned long long dbg_entry = (p.dbg & 16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    auto dbg_exit = [&]() {
-        if ((p.dbg & 16) && (threadIdx.x & 63) == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row stores have left
-            const long wid = ((long)head * p.nqb + qb) * NW + (threadIdx.x >> 6);
-            p.dbg_buf[(1 << 18) + 4 * wid + 0] = dbg_entry;
-            p.dbg_buf[(1 << 18) + 4 * wid + 3] = __builtin_amdgcn_s_memrealtime();
-        }
-    };
-#else
-    auto dbg_exit = [&]() {};
-#endif
     unsigned to_rescue = 0u;
     for (;;) {
         asm volatile("" : "+v"(tid));
@@ -1250,7 +1068,6 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
         }
         two = true;  // many rows of this block are peaked: the block repeats in two-term mode
     }
-    dbg_exit();
     return to_rescue;
 }
 
@@ -1293,32 +1110,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
     const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int bid = blockIdx.x;
     int parity = 0;   // the mailbox alternates between two words: a wave still reading this block's successor cannot meet the next draw
-#ifdef QATTN_DEV
-    int dbg_round = 0;
-#endif
     for (;;) {
         int tid;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
         tid |= wave_s << 6;
         asm volatile("" : "+v"(tid));
         int resc;
-#ifdef QATTN_DEV
-        // work log (QATTN_V2_DBG=24): per workgroup, per round {block, start, after the block, after its rescues, after the draw}
-        unsigned long long* wlog = nullptr;
-        {
-            QATTN_PARAMS();
-            if ((p.dbg & 8) && p.dbg_buf && dbg_round < 31) wlog = p.dbg_buf + 3 * (1 << 19) + ((long)blockIdx.x * 32 + dbg_round) * 5;
-            if (wlog && threadIdx.x == 0) { wlog[0] = (unsigned long long)bid + 1; wlog[1] = __builtin_amdgcn_s_memrealtime(); }
-            ++dbg_round;
-        }
-#endif
         {
             QATTN_PARAMS();
             resc = run_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, BYTE, ABL, Q16, CHECK, IN16>(p, smem, bid, tid, dynamic ? bcast + parity : nullptr);
         }
-#ifdef QATTN_DEV
-        if (wlog && threadIdx.x == 0) wlog[2] = __builtin_amdgcn_s_memrealtime();
-#endif
         int next_drawn = -1;
         if constexpr (CHECK && !TOKEN && NW == 8 && Q16) {
             // (the 16-bit-V rescue's V areas cover the mailbox: the successor's number -- written before the block's vote barrier -- is taken out first)
@@ -1335,9 +1136,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
                 rescue_pass<D, NW, QK_FMT, V_FMT, CAUSAL, Q16, IN16>(p, smem, tid, bid, resc);
             }
         }
-#ifdef QATTN_DEV
-        if (wlog && threadIdx.x == 0) wlog[3] = __builtin_amdgcn_s_memrealtime();
-#endif
         QATTN_PARAMS();
         int next = -1;
         if (dynamic) {
@@ -1349,9 +1147,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParam
             next = bid + (int)gridDim.x;
             lds_barrier();
         }
-#ifdef QATTN_DEV
-        if (wlog && threadIdx.x == 0) wlog[4] = __builtin_amdgcn_s_memrealtime();
-#endif
         if (next < 0) break;
         bid = next;
     }
@@ -1378,26 +1173,14 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     } else {
         p.sched = nullptr;
     }
-    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes + the Q prefetch's dump slot
+    size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;  // K/V ring + parked Q^T fragments + per-wave vote words + V chunk scale bytes + 1 KiB spare (the removed Q prefetch's dump slot; kept: the allocation is part of the measured launch)
     if (Q16 && NW == 8) lds = (size_t)kLdsAll;   // the fused kernels: the pipelined 16-bit-V pass's ring (5 x 24 KiB), the 16-bit-V rescue's V areas + parked Q^T fragments (all 160 KiB), the words at the end (v2_words_offset)
     static_assert(kP16Stages * (64 * 128 + 64 * 2 * 128) <= kLdsAll - 4096 && kStagesV2 * 2 * 64 * 128 + 8 * kQPerWave * 128 <= kLdsAll - 4096, "the rings stay clear of the words");
-    //  the fused kernels' words -- 16 vote / mailbox words, kVxWords V scale words, the 1 KiB dump slot -- live in the last 4 KiB, which
+    //  the fused kernels' words -- 16 vote / mailbox words, kVxWords V scale words -- live in the last 4 KiB, which
     // the 16-bit-V rescue's parked Q^T fragments (wave 7's slot, behind its eight V areas) deliberately cover: rescue_pass takes the masks and
     // the kernel's block loop the drawn successor OUT before anything is parked there (read-before-clobber, see their comments)
     static_assert(kRescue16VBytes + 8 * kQPerWave * 128 == kLdsAll, "the 16-bit-V rescue's V areas + parked Q^T fragments fill the CU's LDS exactly");
-    static_assert(64 + 4 * kVxWords + 1024 <= 4096, "vote words + V scale words + dump slot fit the last 4 KiB");
-    static_assert(QATTN_QPREFETCH == 0 || !Q16, "the Q prefetch's dump slot overlaps wave 7's parked Q^T fragments in the fused kernels");
-#ifdef QATTN_DEV
-    if (p.lds_pad > 0 && !(Q16 && NW == 8 && p.lds_pad < kLdsAll)) lds = (size_t)p.lds_pad;   // (the fused kernels' words sit at kLdsAll - 4096: no smaller allocation)
-#endif
-#ifdef QATTN_DEV
-    if (CHECK && !CAUSAL && BYTE && NW == 8 && getenv("QATTN_ABL_NONEFF")) {   // dev: the AUTO kernel without the effective-key-count MFMA
-        auto kern0 = attn_fwd_kernel_v2<D, NW, FMT, FMT, false, TOKEN, true, 512, Q16, CHECK>;
-        (void)hipFuncSetAttribute((const void*)kern0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern0, dim3(grid), dim3(NW * 64), lds, st, p);
-        return QATTN_OK;
-    }
-#endif
+    static_assert(64 + 4 * kVxWords <= 4096, "vote words + V scale words fit the last 4 KiB");
     if constexpr (FMT == QATTN_FMT_E4M3 && Q16 && BYTE && NW == 8 && !TOKEN && IN16 == QATTN_FMT_BF16) {
         if (p.stamp_buf) {   // measurement entry: the same kernel with the two clock stamps per wave
             auto kern1 = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 1024, Q16, CHECK>;
@@ -1434,32 +1217,8 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
     // blocks that run two-term P from the start: every block (QATTN_PRECISION_ACCURATE), else the kernel's predicted_r rule
     // (at unit score variance: the blocks whose first row sees fewer than kTwoTermKeys keys)
     p.n_two = p.precision == QATTN_PRECISION_ACCURATE ? p.nqb : 0;
-#ifdef QATTN_DEV
-    if ((p.dbg & 0xffff) >= 256 && !CAUSAL && scale_mode == QATTN_SCALE_HEAD && FMT == QATTN_FMT_E4M3 && NW == 8) {
-        // development: compile-time ablations of the headline kernel (QATTN_V2_DBG = 256 + mask [+16 for the cycle stamp])
-        const int grid = p.B * p.Hq * p.nqb;
-        const size_t lds = (size_t)kStagesV2 * 2 * 64 * D + (size_t)NW * kQPerWave * D + 64 + 4 * kVxWords + 1024;
-        p.n_two = 0; p.peak_r0 = 0.0f; p.total_blocks = grid;
-#define QATTN_ABL_CASE(M)                                                                                          \
-        case M: {                                                                                                  \
-            auto kern = attn_fwd_kernel_v2<D, 8, QATTN_FMT_E4M3, QATTN_FMT_E4M3, false, false, true, M>;           \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);                                       \
-            return QATTN_OK;                                                                                       \
-        }
-        switch ((p.dbg & 15) | ((p.dbg & 32) ? 16 : 0) | ((p.dbg & 64) ? 32 : 0) | ((p.dbg & 128) ? 64 : 0)) {
-            QATTN_ABL_CASE(16) QATTN_ABL_CASE(1) QATTN_ABL_CASE(2) QATTN_ABL_CASE(4) QATTN_ABL_CASE(8) QATTN_ABL_CASE(12) QATTN_ABL_CASE(15) QATTN_ABL_CASE(3) QATTN_ABL_CASE(11)
-            QATTN_ABL_CASE(18) QATTN_ABL_CASE(32) QATTN_ABL_CASE(64) QATTN_ABL_CASE(96)
-            default: break;
-        }
-#undef QATTN_ABL_CASE
-    }
-#endif
     // byte-exponential one-term pass, unless the caller wants the LSE (needs the exact row sum) or exact exponentials
-    bool byte_exp = !p.exact_exp && p.lse == nullptr;
-#ifdef QATTN_DEV
-    if (p.lds_pad == -1) byte_exp = true;  // debugging: LSE from the byte-exponential pass (QATTN_V2_LDS=-1)
-#endif
+    const bool byte_exp = p.lse == nullptr;
     if (scale_mode == QATTN_SCALE_TOKEN) return QATTN_ERR_UNSUPPORTED_FMT;  // routed to the templated kernel (attn_v2_covers)
     if (p.q16 != nullptr) {   // fused step: byte path only (qattn_api.hip); its 16-bit input type is the output's
         if (p.out_fmt == QATTN_FMT_FP16) return launch_attn_v2_f16<FMT, CAUSAL>(p, st);   // (a translation unit of its own, below)
@@ -1471,9 +1230,6 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
 // One translation unit per operand format (build.py: -DQATTN_ONLY_FMT=0|1); without the macro the file provides both.
 template <int FMT>
 static int launch_attn_v2_fmt(const AttnParams& p, int causal, int scale_mode, hipStream_t st) {
-#ifdef QATTN_DEV
-    if (p.waves == 4) return causal ? launch_attn_v2_t<128, 4, FMT, true>(p, scale_mode, st) : launch_attn_v2_t<128, 4, FMT, false>(p, scale_mode, st);
-#endif
     return causal ? launch_attn_v2_t<128, 8, FMT, true>(p, scale_mode, st) : launch_attn_v2_t<128, 8, FMT, false>(p, scale_mode, st);
 }
 #if !defined(QATTN_ONLY_IN16) || QATTN_ONLY_IN16 == 2

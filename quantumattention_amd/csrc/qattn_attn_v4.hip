@@ -442,9 +442,24 @@ __global__ __launch_bounds__(512, 2) void rescue_groups_kernel(const AttnParams 
             // (block-scaled V: the chunk scale bytes straight from global memory, one word per chunk)
             rescue_rows<D, 8, QK_FMT, V_FMT, CAUSAL, TOKEN, false, !TOKEN>(p, smem, kg, vg, r0, wave, lane, bh, kv_head, c, skt, qfrag,
                                                                            (!TOKEN && p.vexp) ? p.vexp + kv_head * p.vexp_stride : nullptr);
+            // (fused entry's debug output; the row is re-derived from scalars + the lane index: nothing more is live across the call above)
             __syncthreads();   // (the next group's K prefetch areas alias this one's merge slots)
         }
     }
+}
+
+// The fused entry's row_path output for the rows the rescue launch recomputes (two-term fp8 P on the fp8 V): derived from the same flag
+// words, by a launch of its own that exists only when the caller asked for the output -- a store inside rescue_groups_kernel cost its
+// D = 256 instantiation (256 registers) a spill.  One thread per query row of the blocks from blk_lo on.
+template <int D>   // (one instance per translation unit of this file)
+__global__ void mark_rescued_rows_kernel(const unsigned* flags, unsigned char* path, int Sq, int blk_lo, int blk_n) {
+    const int ng = (Sq + 31) >> 5;
+    const long bh = blockIdx.x / blk_n;
+    const int blk = blk_lo + (int)(blockIdx.x % blk_n), row = blk * 256 + (int)threadIdx.x;
+    const unsigned* f = flags + bh * ng + blk * 8;
+    int nf = 0;
+    for (int g = 0; g < 8; g++) nf += (blk * 8 + g < ng && f[g] != 0u) ? 1 : 0;
+    if (row < Sq && nf > 0 && nf <= kMaxRescueWaves && f[threadIdx.x >> 5] != 0u) path[bh * Sq + row] = (unsigned char)QATTN_PATH_TWO_TERM;
 }
 
 template <int D, int FMT, bool CAUSAL, bool TOKEN>
@@ -492,7 +507,7 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
     // fewer than two_term_keys keys EVERY block is early, causal or not, whatever Sq; ADVICE r4: clamped by the key count, causal calls
     // with Sq > Skv < 1024 left their later rows on one-term fp8 P)
     else rows_two = min(rows_all, pv16_early_blocks(p.Sq, p.Skv, causal, p.two_term_keys) * 256);
-    const bool byte_exp = !p.exact_exp && p.lse == nullptr;
+    const bool byte_exp = p.lse == nullptr;
     const bool rescue = p.peak_r0 > 0.0f && rows_two < p.Sq;
     if (rescue) {
         if (!p.flags) return QATTN_ERR_WORKSPACE;
@@ -526,6 +541,10 @@ static int launch_v4_full_d(const AttnParams& pin, int fmt, int causal, int scal
         if (rc == QATTN_OK && rescue) rc = launch_rescue_d<D>(p, fmt, causal, scale_mode, rows_two, st);
     } else {
         if (rc == QATTN_OK && rescue && group_rescue) rc = launch_rescue_head<D>(p, fmt, causal, rows_two, st);
+    }
+    if (rc == QATTN_OK && rescue && group_rescue && p.path != nullptr) {
+        const int blk_lo = rows_two / 256, blk_n = ceil_div(p.Sq, 256) - blk_lo;
+        if (blk_n > 0) hipLaunchKernelGGL(mark_rescued_rows_kernel<D>, dim3(p.B * p.Hq * blk_n), dim3(256), 0, st, p.flags, p.path, p.Sq, blk_lo, blk_n);
     }
     if (rc == QATTN_OK && rescue) rc = launch_v4_d<D, false>(p, fmt, causal, scale_mode, rows_two, p.Sq, group_rescue ? 3 : 7, st);
     if (side) {   // (joined on every path: a capture must not end with the side stream still forked)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/qattn.h"
+#include "../../include/qattn_measure.h"
 
 namespace qattn {
 
@@ -19,7 +20,13 @@ constexpr int kChunkKeys = 64;  // keys per K/V fragment chunk (one PV MFMA K-di
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------------------
-// Fragment layouts (include/qattn.h).  Offsets are in bytes from the start of the 64-key chunk (64*D bytes).
+// Fragment layouts QATTN_LAYOUT_* (private to the library; S zero-padded to Sp = 64*ceil(S/64), D*Sp bytes per (b,h), c = 64-key chunk):
+//   KFRAG   chunk = [t:2][s:D/64][hh:2][half:2][key:32][16 B]; byte j of a piece = K[64c + 32t + key][64s + 32hh + 16half + j]
+//   VFRAG   chunk = [m:D/32][hh:2][half:2][d:32][16 B]; byte 4w+i of a piece = V[64c + 32half + 8w + 4hh + i][32m + d]
+//           = the A operands of v_mfma_f32_32x32x64_f8f6f4 for S^T = K.Q^T and O^T = V^T.P^T: linear for LDS-DMA, conflict-free ds_read_b128
+//   K16FRAG chunk = [t:2][s:D/16][hh:2][key:32][8 elts], piece = K[64c + 32t + key][16s + 8hh + (0..7)]            (16-bit path)
+//   V16FRAG chunk = [t:2][m:D/32][s:2][hh:2][d:32][8 elts], elt j = V[64c + 32t + 16s + 8(j>>2) + 4hh + (j&3)][32m + d]
+// Offsets below are in bytes from the start of the 64-key chunk (64*D bytes).
 // ---------------------------------------------------------------------------------------------------------
 // K[key_in_chunk][d]  ->  [t:2][s:D/64][hh:2][half:2][key:32][16]
 template <int D>
@@ -199,7 +206,7 @@ __device__ __forceinline__ int2 quant8(const uint4& raw, float scale, float rinv
     // Per pair of elements: unpack (2 VALU), v_pk_mul_f32, tie test on the packed low halves (v_perm, v_pk_add_u16,
     // v_pk_min_u16), v_cvt_pk_bf16_f32, clamp of the packed bf16 magnitudes (and, v_pk_min_u16, and-or), and one
     // v_cvt_scalef32_pk_{fp8,bf8}_bf16 at scale 1.0 -- bit-identical to unpack -> v_med3_f32 -> v_cvt_pk_fp8_f32 for every
-    // finite bf16 (tools/cvt_bf16_fp8_probe.hip) and 11 instead of 17 VALU per pair: the pre-pass is VALU-bound.
+    // finite bf16 (tools/probes/cvt_bf16_fp8_probe.hip) and 11 instead of 17 VALU per pair: the pre-pass is VALU-bound.
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));

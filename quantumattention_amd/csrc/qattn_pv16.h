@@ -439,7 +439,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
         // PV(u - 1) and QK^T(u) as one sequence: all a trip's LDS latency in one place.  The first two k-steps' transposed reads and the K
         // fragments are requested together; QK^T runs as soon as K is there (the row-sum products cover part of that wait), the other two
         // k-steps' reads are requested behind it and land under the first eight PV products.  (Requested one k-step ahead, as pv() does it,
-        // every k-step waited ~150 cycles for its operands: 1400 cycles per trip for 830 of products -- dev stamps, tools/pv16_phases.py.)
+        // every k-step waited ~150 cycles for its operands: 1400 cycles per trip for 830 of products -- dev stamps, profiles/r04/pv16_phase_stamps.log.)
         auto pv_qk = [&](int slot_v, int slot_k) {
             static_assert(MB == 4, "register sets of eight transposed reads");
             const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(smem + slot_v * STAGE + CH);

@@ -315,322 +315,9 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
     }
 }
 
-#ifdef QATTN_DEV
-// ---------------------------------------------------------------------------------------------------------
-// EXPERIMENT, dev library only (QATTN_ONE_READ=1; results in profiles/r02_oneread.md): a one-read pre-pass for head-wise K and
-// V (the two-pass form reads every tensor twice).  Correct (bit-exact on the quantiser tests) and 6 %
-// faster than the two passes at C2 (0.111 vs 0.118 ms for K and V), which is not worth a persistent kernel whose speed
-// depends on a whole team of workgroups being resident together -- the product keeps the two passes.
-// A head is cut into NS slices; a TEAM of NS persistent workgroups (one per CU, neighbours on one XCD) walks heads
-// team, team + nteams, ...  A workgroup is one PRODUCER wave and eight CONSUMER waves around two slice buffers in LDS;
-// no s_barrier in the steady state, the waves hand over through counters in LDS:
-//   producer, head j:  its slice has landed in buffer j&1 (LDS-DMA, the only read of HBM) -> start the DMA of head j+1
-//                      into the other buffer as soon as the consumers have left it -> abs-max of the slice from LDS ->
-//                      publish it as an 8-byte {tag, value} granule (relaxed agent-scope store: the data is the flag,
-//                      cdna_hip_programming.md Guideline 16 R2) -> sweep the head's NS granules until all carry the tag
-//                      -> scale and ready[j&1] = j+1.
-//   consumer, head j:  wait for ready[j&1], then each wave quantises 32-row units on its own: the unit's rows into
-//                      registers, the fp8 fragment image written IN PLACE over the unit's 16-bit rows (in-order LDS, no
-//                      other wave touches the unit), coalesced copy-out, done[j&1] += 1.
-// The exchange and the consumers' stores run under the read of the next head.  Two earlier forms -- all phases back to
-// back in one workgroup (0.132 ms for K and V at C2), and the same with the next slice prefetched but s_barrier phases
-// (0.148 ms) -- lost to the two passes (0.118 ms): at one or two workgroups per CU every phase is a latency chain.
-// Co-residency of a team is a speed assumption only: the sweep is bounded, and a producer whose peers do not show up
-// reduces whole heads from global memory itself from then on (slow, correct, no dependency).  Granules are zeroed by the
-// launcher every call and each is written once per call.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kSliceBytes = 64 * 1024;  // two of them fit the 160 KiB of LDS
-constexpr int kMaxSlices = 64;          // per head: one granule per lane of the sweeping wave
-constexpr unsigned kGranuleTag = 1u;
-constexpr int kTeamConsumers = 8;
-constexpr int kTeamThreads = 64 * (1 + kTeamConsumers);
-
-struct OneReadJobs {
-    const unsigned char* x[2];   // k, v: [G, S, D] 16-bit
-    unsigned char* out[2];       // KFRAG / VFRAG payloads
-    float* scale[2];             // [G]
-    unsigned long long* granules;  // [2 * G][NS]
-    int G, S, NS, rows_per_slice, slice_bytes;
-    int nteams;                  // teams in all (a multiple of 8 unless there are fewer heads)
-    int dbg;
-};
-
-// The V half of vfrag_copy_out for one 32-key unit staged row-major (VSTRIDE-byte rows) at `img`, by one wave, in two
-// steps so that the stores can be issued later than the LDS reads: gather (transposed dwords into registers) and store.
-template <int D, int VSTRIDE>
-__device__ __forceinline__ void vfrag_gather_unit(const unsigned char* img, int lane, int half, uint2* o) {   // o[(D / 64) * 4]
-#pragma unroll
-    for (int kk = 0; kk < D / 64; kk++) {
-        const int blk = (2 * kk + half) * 64 + lane;   // the blocks of vfrag_copy_out whose bit 6 is `half`
-        const int wh = blk & 1, hh = (blk >> 3) & 1;
-        const int dq = ((blk >> 1) & 3) + 4 * ((blk >> 5) & 1), m = ((blk >> 4) & 1) + 2 * (blk >> 7);
-        const int d0 = 32 * m + 4 * dq;
-        unsigned t[2][4];
-#pragma unroll
-        for (int wi = 0; wi < 2; wi++) {
-            const unsigned char* src = img + (8 * (2 * wh + wi) + 4 * hh) * VSTRIDE + d0;
-            const unsigned r0 = *reinterpret_cast<const unsigned*>(src), r1 = *reinterpret_cast<const unsigned*>(src + VSTRIDE);
-            const unsigned r2 = *reinterpret_cast<const unsigned*>(src + 2 * VSTRIDE), r3 = *reinterpret_cast<const unsigned*>(src + 3 * VSTRIDE);
-            const unsigned t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
-            const unsigned t2 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), t3 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
-            t[wi][0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
-            t[wi][1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
-            t[wi][2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
-            t[wi][3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) o[kk * 4 + j] = make_uint2(t[0][j], t[1][j]);
-    }
-}
-template <int D>
-__device__ __forceinline__ void vfrag_store_unit(unsigned char* og_chunk, int lane, int half, const uint2* o) {
-#pragma unroll
-    for (int kk = 0; kk < D / 64; kk++) {
-        const int blk = (2 * kk + half) * 64 + lane;
-        const int wh = blk & 1, hh = (blk >> 3) & 1;
-        const int dq = ((blk >> 1) & 3) + 4 * ((blk >> 5) & 1), m = ((blk >> 4) & 1) + 2 * (blk >> 7);
-        unsigned char* dst = og_chunk + ((((m * 2 + hh) * 2 + half) * 32 + 4 * dq) << 4) + 8 * wh;
-#pragma unroll
-        for (int j = 0; j < 4; j++) *reinterpret_cast<uint2*>(dst + 16 * j) = o[kk * 4 + j];
-    }
-}
-
-template <int D, int IN_FMT, int OUT_FMT>
-__global__ __launch_bounds__(kTeamThreads) void quant_team_kernel(const OneReadJobs jb, const int numerics) {
-    constexpr int ROWB = D * 2;                    // bytes of one 16-bit row
-    constexpr int VPR = D / 8;                     // 16-byte input vectors per row
-    constexpr int UVEC = 32 * VPR / 64;            // vectors per lane and 32-row unit
-    constexpr int UBYTES = 32 * ROWB;              // a unit's 16-bit rows; its fp8 image (<= UBYTES / 2 + pad) replaces them
-    constexpr int VSTRIDE = D + 4;
-    constexpr int NCW = kTeamConsumers;
-    constexpr int WBYTES = kSliceBytes / NCW;      // a consumer wave's share of a slice buffer: 8 KiB = 8 DMA instructions
-    constexpr int UPW = WBYTES / UBYTES;           // units per wave (1 at D = 128, 2 at D = 64)
-    constexpr int NDMA = WBYTES / 1024;
-    static_assert(UPW >= 1 && UPW * UVEC == 8 && NDMA == 8, "a wave owns 8 KiB of every slice");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 slice buffers][arrive 2][amax 2][ready 2][scale 2]
-    unsigned* ctrl = reinterpret_cast<unsigned*>(lds + 2 * kSliceBytes);
-    unsigned* arrive = ctrl;
-    unsigned* amaxw = ctrl + 2;
-    unsigned* ready = ctrl + 4;
-    float* sc = reinterpret_cast<float*>(ctrl + 6);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TH = 2 * jb.G, NS = jb.NS, S = jb.S;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int team = (idx / NS) * 8 + xcd, slice = idx % NS;   // a team's workgroups are neighbours in one XCD's dispatch order
-    if (team >= jb.nteams) return;
-    if (tid < 6) ctrl[tid] = 0;
-    __syncthreads();
-    const int r0 = slice * jb.rows_per_slice;
-    const int nrows = min(jb.rows_per_slice, S - r0);   // >= 1: NS = ceil(S / rows_per_slice)
-    const int valid = nrows * ROWB;
-    const long Sp = (long)((S + 63) / 64) * 64;
-
-    if (wave == NCW) {
-        // ---------------------------------- coordinator: the head's abs-max exchange ----------------------------------
-        const float inv_qmax = (float)(1.0 / (double)(OUT_FMT == QATTN_FMT_E4M3 ? 448.0 : 57344.0));
-        bool alone = false;   // a sweep timed out once -> stop waiting for peers
-        int j = 0;
-        for (int h = team; h < TH; h += jb.nteams, j++) {
-            const int t = h >= jb.G, g = h - t * jb.G, b = j & 1;
-            const unsigned need = NCW * (unsigned)((j >> 1) + 1);
-            while (__hip_atomic_load(arrive + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-            const unsigned m16 = __hip_atomic_exchange(amaxw + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (reset for head j + 2)
-            const unsigned mine = __float_as_uint(load16f<IN_FMT>((unsigned short)m16));
-            unsigned long long* gr = jb.granules + (long)h * NS;
-            if (lane == 0) __hip_atomic_store(gr + slice, ((unsigned long long)kGranuleTag << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned best = 0;
-            bool got = false;
-#ifdef QATTN_DEV
-            if (jb.dbg & 1) { got = true; best = mine; }
-#endif
-            for (int spin = 0; spin < 4000 && !got && !alone; spin++) {
-                unsigned long long x = ((unsigned long long)kGranuleTag << 32);
-                if (lane < NS) x = __hip_atomic_load(gr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                got = __all((unsigned)(x >> 32) == kGranuleTag);
-                best = (unsigned)x;
-                if (!got) __builtin_amdgcn_s_sleep(2);
-            }
-            if (!got) {
-                // peers missing (the team is not co-resident): reduce the whole head from global memory -- no dependency
-                alone = true;
-                unsigned f0 = 0;
-                const uint4* xh = reinterpret_cast<const uint4*>(jb.x[t] + (long)g * S * ROWB);
-                for (long i = lane; i < (long)S * VPR; i += 64) {
-                    const uint4 v = xh[i];
-                    unsigned a = v.x & 0x7fff7fffu, bb = v.y & 0x7fff7fffu, c = v.z & 0x7fff7fffu, d = v.w & 0x7fff7fffu;
-                    f0 = max(f0, max(max(max(a & 0xffffu, a >> 16), max(bb & 0xffffu, bb >> 16)), max(max(c & 0xffffu, c >> 16), max(d & 0xffffu, d >> 16))));
-                }
-                best = __float_as_uint(load16f<IN_FMT>((unsigned short)f0));
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, off));
-            const float scale = make_scale(__uint_as_float(best), inv_qmax, numerics, IN_FMT);
-            if (lane == 0) {
-                if (slice == 0) jb.scale[t][g] = scale;
-                sc[b] = scale;
-                __hip_atomic_store(ready + b, (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        return;
-    }
-    // ------------------------------- consumers: each owns 8 KiB of either slice buffer -------------------------------
-    const int cw = wave;
-    const int nunits = 2 * ((nrows + 63) / 64);   // both halves of every live 64-row tile: rows past S are written as zeros
-    const bool active = cw * UPW < nunits;
-    // this wave's 8 KiB of head h's slice -> its region of the buffer; addresses past the slice re-read its last 16 bytes
-    auto fetch = [&](int h, unsigned char* region) {
-        const int t = h >= jb.G, g = h - t * jb.G;
-        const unsigned char* xs = jb.x[t] + ((long)g * S + r0) * ROWB;
-#pragma unroll
-        for (int piece = 0; piece < NDMA; piece++) {
-            const int off = min(cw * WBYTES + piece * 1024 + lane * 16, valid - 16);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + off),
-                                             (__attribute__((address_space(3))) void*)(region + piece * 1024), 16, 0, 0);
-        }
-    };
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    if (active) {
-        fetch(team, lds + cw * WBYTES);
-        if (team + jb.nteams < TH) fetch(team + jb.nteams, lds + kSliceBytes + cw * WBYTES);
-    }
-    // A wave's fp8 output of one head, gathered in fragment order: K 4 x 16 B, V 8 x 8 B per lane, at D = 64 and 128 alike.
-    struct Held { uint2 w[8]; };
-    // Quantise the rows of head hq (in registers, ready slot bq) through the staging `region`, gather the fragment image
-    // back into registers, then hand the region to the LDS-DMA of head hnext (< 0: none).  The caller has read the
-    // region's own rows into registers already.
-    auto quantise = [&](const uint4 (&rows)[8], int hq, int jq, unsigned char* region, int hnext, Held& held) {
-        const int t = hq >= jb.G, bq = jq & 1;
-        while (__hip_atomic_load(ready + bq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(jq + 1)) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        const float scale = *reinterpret_cast<volatile float*>(sc + bq);
-        const float rinv = 1.0f / scale;
-#pragma unroll
-        for (int uu = 0; uu < UPW; uu++) {
-            unsigned char* ub = region + uu * UBYTES;   // (units past the slice are all padding: zeros, never stored)
-            if (t == 0) {
-#pragma unroll
-                for (int u = 0; u < UVEC; u++) {
-                    const int vec = u * 64 + lane;
-                    const int2 q8 = quant8<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale, rinv);   // (fp16: the exact sequence, out of line)
-                    const int o = kfrag_offset<D>(vec / VPR, (vec % VPR) * 8);   // key < 32: the t = 0 half of the image
-                    *reinterpret_cast<int2*>(ub + o + ((o >> 9) << 4)) = q8;
-                }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < D / 32; u++) {
-                    const int i = u * 64 + lane;
-                    const uint4 val = *reinterpret_cast<const uint4*>(ub + i * 16 + ((i >> 5) << 4));
-                    held.w[2 * (uu * (D / 32) + u)] = make_uint2(val.x, val.y);
-                    held.w[2 * (uu * (D / 32) + u) + 1] = make_uint2(val.z, val.w);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < UVEC; u++) {
-                    const int vec = u * 64 + lane;
-                    const int2 q8 = quant8<IN_FMT, OUT_FMT>(rows[uu * UVEC + u], scale, rinv);
-                    unsigned char* dst = ub + (vec / VPR) * VSTRIDE + (vec % VPR) * 8;
-                    *reinterpret_cast<int*>(dst) = q8.x;
-                    *reinterpret_cast<int*>(dst + 4) = q8.y;
-                }
-                asm volatile("" ::: "memory");
-                vfrag_gather_unit<D, VSTRIDE>(ub, lane, (cw * UPW + uu) & 1, held.w + uu * (D / 64) * 4);
-            }
-        }
-        if (hnext >= 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staged image has been read back
-            fetch(hnext, region);
-        }
-    };
-    // The stores of head hq's gathered output.  Issued one iteration after the gather, right after the wait for the next
-    // rows: a store issued just before an LDS-DMA would have to be acknowledged before `s_waitcnt vmcnt(8)` lets that DMA's
-    // predecessor through (one counter for loads and stores), which cost 30 us of 111 at C2.
-    auto flush = [&](int hq, const Held& held) {
-        const int t = hq >= jb.G, g = hq - t * jb.G;
-#ifdef QATTN_DEV
-        if (jb.dbg & 4) return;
-#endif
-#pragma unroll
-        for (int uu = 0; uu < UPW; uu++) {
-            const int unit = cw * UPW + uu;
-            if (unit >= nunits) continue;
-            const int tile = unit >> 1, half = unit & 1;
-            const long chunk = ((long)g * Sp + r0 + tile * 64) * D;   // the 64-row fragment chunk this unit is half of
-            if (t == 0) {
-                uint4* og = reinterpret_cast<uint4*>(jb.out[0] + chunk + half * (32 * D));
-#pragma unroll
-                for (int u = 0; u < D / 32; u++) {
-                    const uint2 lo = held.w[2 * (uu * (D / 32) + u)], hi = held.w[2 * (uu * (D / 32) + u) + 1];
-                    og[u * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-            } else {
-                vfrag_store_unit<D>(jb.out[1] + chunk, lane, half, held.w + uu * (D / 64) * 4);
-            }
-        }
-    };
-    // Iteration j: head j's rows go to registers and its abs-max to the coordinator; head j - 2's output is stored; head
-    // j - 1 is quantised (its exchange has had a whole iteration), staged in head j's region, which then takes head j + 2.
-    uint4 prev[8];
-    Held held;
-    int j = 0;
-    for (int h = team; h < TH; h += jb.nteams, j++) {
-        const int b = j & 1;
-        unsigned char* region = lds + b * kSliceBytes + cw * WBYTES;
-        uint4 raw[8];
-        unsigned m = 0;
-        if (active) {
-            // head j's rows have landed when at most the NDMA loads of head j + 1 are outstanding (loads return in order)
-            if (h + jb.nteams < TH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (j > 1) flush(h - 2 * jb.nteams, held);
-            unsigned m0 = 0, m1 = 0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int vec = u * 64 + lane;   // within the wave's region: unit (u / UVEC), row (vec % (64 * UVEC)) / VPR
-                const int row = cw * (WBYTES / ROWB) + vec / VPR;
-                raw[u] = make_uint4(0, 0, 0, 0);
-                if (row < nrows) raw[u] = *reinterpret_cast<const uint4*>(region + vec * 16);
-                unsigned a = raw[u].x & 0x7fff7fffu, bb = raw[u].y & 0x7fff7fffu, c = raw[u].z & 0x7fff7fffu, d = raw[u].w & 0x7fff7fffu;
-                u16x2 pa, pb, pc, pd, p0, p1;
-                __builtin_memcpy(&pa, &a, 4); __builtin_memcpy(&pb, &bb, 4); __builtin_memcpy(&pc, &c, 4); __builtin_memcpy(&pd, &d, 4);
-                __builtin_memcpy(&p0, &m0, 4); __builtin_memcpy(&p1, &m1, 4);
-                p0 = __builtin_elementwise_max(p0, __builtin_elementwise_max(pa, pb));
-                p1 = __builtin_elementwise_max(p1, __builtin_elementwise_max(pc, pd));
-                __builtin_memcpy(&m0, &p0, 4); __builtin_memcpy(&m1, &p1, 4);
-            }
-            m = max(max(m0 & 0xffffu, m0 >> 16), max(m1 & 0xffffu, m1 >> 16));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-        }
-        if (lane == 0) {
-            if (m) __hip_atomic_fetch_max(amaxw + b, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(arrive + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (!active) continue;
-#ifdef QATTN_DEV
-        if (jb.dbg & 2) {
-            if (h + 2 * jb.nteams < TH) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); fetch(h + 2 * jb.nteams, region); }
-            continue;
-        }
-#endif
-        if (j > 0) quantise(prev, h - jb.nteams, j - 1, region, h + 2 * jb.nteams < TH ? h + 2 * jb.nteams : -1, held);
-        else if (h + 2 * jb.nteams < TH) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fetch(h + 2 * jb.nteams, region);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) prev[u] = raw[u];
-    }
-    if (active && j > 0) {
-#ifdef QATTN_DEV
-        if (jb.dbg & 2) return;
-#endif
-        if (j > 1) flush(team + (j - 2) * jb.nteams, held);
-        quantise(prev, team + (j - 1) * jb.nteams, j - 1, lds + ((j - 1) & 1) * kSliceBytes + cw * WBYTES, -1, held);
-        flush(team + (j - 1) * jb.nteams, held);
-    }
-}
-
-#endif  // QATTN_DEV
+// (Round 2's one-read experiment -- slices of a head held in LDS by persistent TEAMS of workgroups, abs-max exchanged through tagged
+// granules in global memory: bit-exact, 6 % faster on K and V, 1 % on the step, speed dependent on whole teams being co-resident -- lived here
+// behind QATTN_DEV until round 5; measurements in profiles/r02_oneread.md, code in the history up to commit 16f0f18.)
 
 // ---------------------------------------------------------------------------------------------------------
 // host-side dispatch
@@ -718,28 +405,6 @@ extern "C" size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv) {
     return qattn::kMomentSplits * ((nq + 2 * nk) + (nq + nk)) * sizeof(unsigned);
 }
 
-#ifdef QATTN_DEV
-template <int D>
-static bool launch_quant_oneread(const qattn::OneReadJobs& jb, int in_fmt, int out_fmt, int numerics, hipStream_t st) {
-    using namespace qattn;
-    const size_t lds = 2 * (size_t)kSliceBytes + 64;
-    dim3 grid((jb.nteams + 7) / 8 * 8 * jb.NS), block(kTeamThreads);
-    auto go = [&](auto kern) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        hipLaunchKernelGGL(kern, grid, block, lds, st, jb, numerics);
-        return true;
-    };
-    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E4M3) return go(quant_team_kernel<D, QATTN_FMT_BF16, QATTN_FMT_E4M3>);
-    if (in_fmt == QATTN_FMT_BF16) return go(quant_team_kernel<D, QATTN_FMT_BF16, QATTN_FMT_E5M2>);
-    if (out_fmt == QATTN_FMT_E4M3) return go(quant_team_kernel<D, QATTN_FMT_FP16, QATTN_FMT_E4M3>);
-    return go(quant_team_kernel<D, QATTN_FMT_FP16, QATTN_FMT_E5M2>);
-}
-
-static bool one_read_enabled() {
-    static const int on = [] { const char* e = getenv("QATTN_ONE_READ"); return e ? atoi(e) : 0; }();
-    return on != 0;
-}
-#endif  // QATTN_DEV
 
 template <int D>
 static int launch_quant_multi(const QuantJobs& jobs, int in_fmt, int out_fmt, int numerics, dim3 grid, int ztop, hipStream_t st) {
@@ -808,48 +473,11 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
     const int Gmax = B * (Hq > Hkv ? Hq : Hkv), Smax = Sq > Skv ? Sq : Skv;
     {
         const int splits = amax_splits(Sq, Skv, D);
-#ifdef QATTN_DEV
-        // (experiment: the one-read team kernel for head-wise K and V; one workgroup per CU, whole teams per XCD)
-        const int NS = (Skv + kSliceBytes / (D * 2) - 1) / (kSliceBytes / (D * 2));
-        const int tpx = NS >= 1 ? 32 / NS : 0;
-        const bool oneread = !tok && tpx >= 1 && D <= 128 && !vblock && !ext_amax && one_read_enabled();   // (the team kernel scales V per head)
-#else
-        const bool oneread = false;
-#endif
-        dim3 grid(splits, oneread ? B * Hq : Gmax, oneread ? 1 : npass), block(256);   // (block-scaled V, supplied abs-max: not in the pass)
-        if (oneread) { jobs.zmap[0] = 0; }
-        if (oneread || npass > 0) {
+        dim3 grid(splits, Gmax, npass), block(256);   // (block-scaled V, supplied abs-max: not in the pass)
+        if (npass > 0) {
             if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, splits, 0);
             else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, splits, 0);
         }
-#ifdef QATTN_DEV
-        if (oneread) {
-            static unsigned long long* granules = nullptr;   // dev only: 2 * G * NS granules, one allocation for the process
-            static size_t granule_cap = 0;
-            const size_t gbytes = 2 * (size_t)B * Hkv * NS * sizeof(unsigned long long);
-            if (gbytes > granule_cap) {
-                if (granules) (void)hipFree(granules);
-                if (hipMalloc((void**)&granules, gbytes) != hipSuccess) return QATTN_ERR_LAUNCH;
-                granule_cap = gbytes;
-            }
-            if (hipMemsetAsync(granules, 0, gbytes, st) != hipSuccess) return QATTN_ERR_LAUNCH;
-            OneReadJobs jb;
-            jb.x[0] = (const unsigned char*)k; jb.x[1] = (const unsigned char*)v;
-            jb.out[0] = (unsigned char*)k8; jb.out[1] = (unsigned char*)v8;
-            jb.scale[0] = scale_k; jb.scale[1] = scale_v;
-            jb.granules = granules;
-            jb.G = B * Hkv; jb.S = Skv; jb.NS = NS; jb.rows_per_slice = kSliceBytes / (D * 2); jb.slice_bytes = kSliceBytes;
-            jb.dbg = getenv("QATTN_TEAM_DBG") ? atoi(getenv("QATTN_TEAM_DBG")) : 0;
-            jb.nteams = 8 * tpx < 2 * jb.G ? 8 * tpx : 2 * jb.G;
-            const bool ok = D == 64 ? launch_quant_oneread<64>(jb, in_fmt, out_fmt, numerics, st) : launch_quant_oneread<128>(jb, in_fmt, out_fmt, numerics, st);
-            if (!ok) return QATTN_ERR_LAUNCH;
-            if (skip_q_payload) return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
-            dim3 gq(((Sq + 63) / 64 + kQuantTilesPerBlock - 1) / kQuantTilesPerBlock, B * Hq, 1);   // Q payload: the two-pass quantise over job 0 only
-            const int rq = D == 64 ? launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, gq, 0, st) : launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, gq, 0, st);
-            if (rq != QATTN_OK) return rq;
-            return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
-        }
-#endif
     }
     // the quantise pass walks jobs ztop, ztop-1, ...: with skip_q_payload only v and k (blockIdx.z = 0, 1)
     dim3 grid((((skip_q_payload ? Skv : Smax) + 63) / 64 + kQuantTilesPerBlock - 1) / kQuantTilesPerBlock, skip_q_payload ? B * Hkv : Gmax, skip_q_payload ? 2 : 3);

@@ -134,8 +134,8 @@ def fp8_quant_attention_forward(
     per-head max |x| of query / key from the kernel that produced them; the abs-max launch then has nothing to read --
     the hand-off the reference gets from Inductor fusing the quantiser into the producer.  ssq_q / ssq_k (fp32 [B,H], both or
     neither): per-head sums of squares, which keep precision="auto" its score-spread estimate when the abs-max pass is skipped.
-    amax_v (fp32 [B,Hkv]): the same for value, read only where V has one scale per head (fp16 inputs at D = 128; elsewhere the fused
-    step scales V per 64-key chunk inside the quantise pass and needs no abs-max of it)."""
+    amax_v (fp32 [B,Hkv]): the same for value, read only where V has one scale per head (token-wise scales, or more than 16384 keys per
+    head; elsewhere the fused step scales V per 64-key chunk inside the quantise pass and needs no abs-max of it: include/qattn.h PATH TABLE)."""
     return _native.fp8_quant_attention_forward(
         query, key, value, is_causal=is_causal, scaling=scaling_method, fp8_dtype=_native.fp8_dtype_of(fp8_format),
         numerics=numerics, sm_scale=0.0 if scale is None else float(scale), precision=precision, amax_q=amax_q, amax_k=amax_k,

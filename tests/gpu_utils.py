@@ -44,7 +44,7 @@ def out_to_f32(t: torch.Tensor) -> np.ndarray:
 
 
 def unpack_frag(buf: np.ndarray, layout: int, B: int, H: int, S: int, D: int) -> np.ndarray:
-    """Invert QATTN_LAYOUT_KFRAG / _VFRAG (include/qattn.h) -> row-major [B,H,Sp,D] (Sp = S padded to 64)."""
+    """Invert QATTN_LAYOUT_KFRAG / _VFRAG (byte maps: csrc/qattn_common.h) -> row-major [B,H,Sp,D] (Sp = S padded to 64)."""
     Sp = (S + 63) // 64 * 64
     x = np.asarray(buf, np.uint8).reshape(B, H, Sp // 64, 64 * D)
     key = np.arange(64)[:, None]

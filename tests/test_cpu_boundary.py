@@ -16,7 +16,8 @@ from tests.conftest import GOLDEN, ROOT
 
 
 def _header_functions():
-    text = open(os.path.join(ROOT, "include", "qattn.h")).read()
+    # the drop-in surface (qattn.h) and the measurement entries (qattn_measure.h)
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("qattn.h", "qattn_measure.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(qattn_[a-z0-9_]+)\s*\(", text)))
 

@@ -122,7 +122,7 @@ def test_dominant_exact_top_key_over_a_crushed_rest(S, D, scaling, mult):
 
 def _heavy_inputs(S, D, K, late, seed, gap=9.0, H=1):
     """K keys that CARRY every row that sees them: their scores sit `gap` nats above an N(0,1) background with 0.15..0.3 nats of
-    spread among themselves (tools/sim_heavy.py).  q = q0 + a u, heavy keys = a u + jitter, a^2 / sqrt(D) = gap; every
+    spread among themselves (tools/models/sim_heavy.py).  q = q0 + a u, heavy keys = a u + jitter, a^2 / sqrt(D) = gap; every
     other key (and q0) has no component along u, so the background scores stay N(0,1).  late: heavy keys only among the last
     256 positions (nothing of them in the first chunks: the kernel's first-chunk forecast cannot see them)."""
     g = torch.Generator().manual_seed(seed)

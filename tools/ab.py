@@ -7,7 +7,7 @@ its own operands, and each (library, precision, path) variant is timed with HIP 
                      [--rounds 7] [--calls 20] [--fp8 e4m3] [--scale 1.0] [--settle 0.5]
   paths: fused = qattn_fp8_quant_attention_forward (the bench step), attn = qattn_fp8_attention_forward on pre-quantised
          operands, quant = qattn_quant_qkv_fp8.
-  default libraries: new=quantumattention_amd/libqattn_hip.so r4=tools/ab_libs/libqattn_r4.so (if present)
+  default libraries: new=quantumattention_amd/libqattn_hip.so r5=tools/ab_libs/libqattn_r5.so (round 5's product library; a missing library is an error)
   --token: token-wise scales of q and k
   name=path@VAR=VAL[@VAR2=VAL2]: environment set around that variant's calls (dev library switches that are read per call)
 Prints median / min ms per variant and the ratio to the first library's variant of the same (precision, path).
@@ -108,10 +108,11 @@ def main():
         parts = rest.split("@")
         libs.append([n, parts[0]])
         envs[n] = dict(e.split("=", 1) for e in parts[1:])
-    if not libs:
-        libs = [["new", os.path.join(ROOT, "quantumattention_amd", "libqattn_hip.so")]]
-        if os.path.exists(os.path.join(ROOT, "tools", "ab_libs", "libqattn_r4.so")):
-            libs.append(["r4", os.path.join(ROOT, "tools", "ab_libs", "libqattn_r4.so")])
+    if not libs:   # default: the product library against the previous round's (tools/ab_libs travels to the GPU box: it is NOT in .gpurunignore)
+        libs = [["new", os.path.join(ROOT, "quantumattention_amd", "libqattn_hip.so")], ["r5", os.path.join(ROOT, "tools", "ab_libs", "libqattn_r5.so")]]
+    for n, p in libs:   # never silently drop a column: a missing baseline is an error
+        if not os.path.exists(p):
+            sys.exit(f"tools/ab.py: library {n}={p} does not exist (build it, e.g. from the previous round's tag: see tools/README.md)")
     B, H, S, D = (int(x) for x in a.shape.split(","))
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))

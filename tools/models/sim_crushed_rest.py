@@ -2,11 +2,11 @@
 """Model behind kCrushMean (qattn_attn.h row_is_peaked): rows whose top key is the exact reference and 8 .. 10 nats above an
 otherwise flat row.  The exact-top rule judged such a row by its rest alone; the rest's P' then sits at or below e4m3's smallest
 normal (2^-6 against the reference 2^5) and is crushed.  Bins the rows the rule accepted by the mean P' of their other keys and
-prints the worst one-term error per bin (tools/sim_exact_top_n.py arithmetic; found by tools/fuzz_parity.py).
-   python tools/sim_crushed_rest.py"""
+prints the worst one-term error per bin (tools/models/sim_exact_top_n.py arithmetic; found by tools/fuzz_parity.py).
+   python tools/models/sim_crushed_rest.py"""
 import math, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from sim_exact_top_n import sim, rules
 from sim_exact_top import ref_out

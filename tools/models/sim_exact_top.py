@@ -7,12 +7,12 @@ effective key count of the REST of the row (top key removed) instead of by R:
 
     peaked = N_eff < 192  or  (R < 24 and not (m_run == m_true and N_eff_rest >= T))
 
-Model (tools/sim_heavy.py arithmetic): fraction of rows flagged by the old and the new rule and the worst error among the rows
-each accepts, on flat, causal, scaled (q x a) and two-outlier data.   python tools/sim_exact_top.py
+Model (tools/models/sim_heavy.py arithmetic): fraction of rows flagged by the old and the new rule and the worst error among the rows
+each accepts, on flat, causal, scaled (q x a) and two-outlier data.   python tools/models/sim_exact_top.py
 """
 import math, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from sim_heavy import E4M3_LUT, E5M2_LUT
 

@@ -3,10 +3,10 @@
 reference (exact), the rest is accepted when  sum_rest P'^2 < t^2 + (l_rest - t)^2 / (n - 2),  t = l / 24  -- which proves
 that no other weight exceeds 1 / 24 (Cauchy-Schwarz on the n - 2 remaining keys) and that the statistical budget 1 / 192 holds.
 Counts flagged 32-row groups of flat causal / non-causal heads under the old and the new rule, and the worst one-term error among
-the rows each accepts.   python tools/sim_exact_top_n.py"""
+the rows each accepts.   python tools/models/sim_exact_top_n.py"""
 import math, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from sim_heavy import E4M3_LUT, E5M2_LUT
 from sim_exact_top import ref_out

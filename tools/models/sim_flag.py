@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Accuracy model for the one-term fp8-P path: per-row error vs the statistics a kernel could flag rows with.
-Test infrastructure (uses the oracle).   python tools/sim_flag.py"""
+Test infrastructure (uses the oracle).   python tools/models/sim_flag.py"""
 import math, os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 import oracle  # noqa: E402
-from tools.sim_kernel import sim_head  # noqa: E402
+from tools.models.sim_kernel import sim_head  # noqa: E402
 
 b16 = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)
 

@@ -2,13 +2,13 @@
 """Accuracy model for a refined peakedness rule: a one-term row is accepted when R = 1 / w_max >= R0, or when R >= R_lo and the
 rest of the row is flat by the same measure, R2 = (1 - w_1) / w_2 >= R0 with w_2 the largest weight outside the top key's 64-key
 chunk (what the kernel can track with one v_med3 per chunk).  Rows with ONE planted dominant key are the case the plain rule
-rejects needlessly.   python tools/sim_flag2.py"""
+rejects needlessly.   python tools/models/sim_flag2.py"""
 import math, os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 import oracle  # noqa: E402
-from tools.sim_kernel import sim_head  # noqa: E402
+from tools.models.sim_kernel import sim_head  # noqa: E402
 
 b16 = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)
 

@@ -5,9 +5,9 @@ The kernel gets sum P'^2 from the matrix pipe: the e4m3 byte of P' read as an e5
 exponent field weighs twice as much), so one more row-sum MFMA with the B format switched to bf8 accumulates it.
 
 NumPy/torch model (test infrastructure; uses the oracle): the construction of tests/test_gpu_precision.py, the one-term
-byte-exponential kernel arithmetic of tools/sim_kernel.py, both statistics, and the worst error among the rows each rule accepts.
+byte-exponential kernel arithmetic of tools/models/sim_kernel.py, both statistics, and the worst error among the rows each rule accepts.
 
-  python tools/sim_heavy.py
+  python tools/models/sim_heavy.py
 """
 import math
 import os
@@ -16,7 +16,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 import oracle  # noqa: E402
 
 E4M3_LUT = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float()

@@ -2,7 +2,7 @@
 """Numpy/torch model of the HIP attention kernel's numerics (chunked online softmax, fp8 P, deferred rescale) used
 to budget accuracy before changing the kernel.  Test infrastructure only (uses the oracle as the reference).
 
-  python tools/sim_kernel.py
+  python tools/models/sim_kernel.py
 """
 import math
 import sys
@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 import oracle  # noqa: E402
 
 E4M3_LUT = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float()  # byte -> value

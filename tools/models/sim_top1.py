@@ -2,9 +2,9 @@
 """Accuracy model: one-term byte-exponential P with the row's TOP key compensated exactly; error vs R2 = l / p_2nd."""
 import math, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root
 import oracle
-from tools.sim_kernel import E4M3_LUT
+from tools.models.sim_kernel import E4M3_LUT
 b16 = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)
 
 def phat_matrix(s_all, c, shift=5.0, thr=3.0, bias=-0.3, chunk=64):

@@ -1,6 +1,6 @@
 // Development probe: does v_cvt_scalef32_pk_{fp8,bf8}_bf16 (scale 1.0) on magnitude-clamped packed bf16 give the same
 // bytes as unpack -> v_med3_f32 -> v_cvt_pk_{fp8,bf8}_f32 for every finite bf16 pattern?  (quant8's last three steps.)
-//   hipcc --offload-arch=gfx950 -O3 tools/cvt_bf16_fp8_probe.hip -o tools/bin/cvt_bf16_fp8_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/cvt_bf16_fp8_probe.hip -o /tmp/cvt_bf16_fp8_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __bf16 b2 __attribute__((ext_vector_type(2)));

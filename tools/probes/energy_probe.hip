@@ -10,7 +10,7 @@
 //     NL ds_read_b128 (operand fragments: conflict-free 16-byte reads), ND global_load_lds_dwordx4 (K/V ring: 1 KiB per wave each, L2-resident source)
 //     a workgroup barrier + vmcnt(0) every second iteration when BAR
 // Test infrastructure only; nothing here is linked into the product.  Build + run on the GPU box:
-//     hipcc --offload-arch=gfx950 -O3 tools/energy_probe.hip -o /tmp/energy_probe && /tmp/energy_probe
+//     hipcc --offload-arch=gfx950 -O3 tools/probes/energy_probe.hip -o /tmp/energy_probe && /tmp/energy_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -67,7 +67,7 @@ __device__ __forceinline__ void valu_block(float (&x)[32], unsigned (&r)[8], flo
 }
 
 template <int NSUM, int NV, int NL, int ND, bool BAR, bool MFMA>
-__global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsigned char* kv, float* sink, int iters) {
+__global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsigned char* kv, float* sink, int iters, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v8i a[4], b[2], ones;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsig
     unsigned slot = 0, goff = 0;
     v4i frag[2];
     frag[0] = v4i{0, 0, 0, 0}; frag[1] = frag[0];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
         if (BAR && (it & 1) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsig
             a[(it + 1) & 3][4] ^= frag[1][1] & 0x07070707;
         }
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) { stamps[2 * (blockIdx.x * 8 + wave)] = t1 - t0; stamps[2 * (blockIdx.x * 8 + wave) + 1] = r1 - r0; }
     float s = s1[0] + s2[0];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsig
     if (s == 1.2345e-30f) sink[0] = s;
 }
 
-struct Ctx { v8i* ops; unsigned char* kv; float* sink; int grid; };
+struct Ctx { v8i* ops; unsigned char* kv; float* sink; int grid; unsigned long long* stamps; };
 
 template <int NSUM, int NV, int NL, int ND, bool BAR, bool MFMA>
 static double run(const Ctx& c, const char* name, double base_ns) {
@@ -165,19 +168,19 @@ static double run(const Ctx& c, const char* name, double base_ns) {
     const int iters = 6000;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     // settle at the power cap: 0.4 s of back-to-back launches, then the median of the following ones
-    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, 200);
+    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, 200, c.stamps);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, iters);
+    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, iters, c.stamps);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms1; CK(hipEventElapsedTime(&ms1, e0, e1));
     const int warm = std::max(3, (int)(400.0 / ms1)), laps = std::max(5, (int)(300.0 / ms1));
-    for (int i = 0; i < warm; i++) hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, iters);
+    for (int i = 0; i < warm; i++) hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, iters, c.stamps);
     std::vector<float> t;
     for (int i = 0; i < laps; i++) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, iters);
+        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(kThreads), kLds, 0, c.ops, c.kv, c.sink, iters, c.stamps);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -185,9 +188,16 @@ static double run(const Ctx& c, const char* name, double base_ns) {
     }
     std::sort(t.begin(), t.end());
     const double ns = (double)t[t.size() / 2] * 1e6 / iters;   // ns per iteration (all waves of the chip advance one iteration)
+    // the clock the chip held inside the last launch: shader cycles / 100 MHz ticks of every wave's loop (median)
+    std::vector<unsigned long long> st(2 * (size_t)c.grid * 8);
+    CK(hipMemcpy(st.data(), c.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> clk;
+    for (size_t w = 0; w < st.size() / 2; w++) if (st[2 * w + 1]) clk.push_back((double)st[2 * w] / (double)st[2 * w + 1] * 0.1);
+    std::sort(clk.begin(), clk.end());
+    const double ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
     const double tf = MFMA ? 8.0 * 2 * 32 * 32 * 64 * (c.grid * 8.0) / (ns * 1e-9) / 1e12 : 0.0;
-    printf("%-46s NSUM %d NV(explicit) %3d NL %2d ND %d BAR %d | %7.1f ns / iteration | %6.0f TFLOP/s (8 products) | %+7.1f ns vs MFMA8+2 (%+5.1f %%)\n", name, NSUM, NV, NL, ND,
-           (int)BAR, ns, tf, base_ns > 0 ? ns - base_ns : 0.0, base_ns > 0 ? 100.0 * (ns - base_ns) / base_ns : 0.0);
+    printf("%-46s NSUM %d NV(explicit) %3d NL %2d ND %d BAR %d | %7.1f ns / iteration = %6.0f cycles at %.3f GHz | %6.0f TFLOP/s (8 products) | %+7.1f ns vs MFMA8+2 (%+5.1f %%)\n", name, NSUM, NV, NL, ND,
+           (int)BAR, ns, ns * ghz, ghz, tf, base_ns > 0 ? ns - base_ns : 0.0, base_ns > 0 ? 100.0 * (ns - base_ns) / base_ns : 0.0);
     fflush(stdout);
     return ns;
 }
@@ -204,6 +214,7 @@ int main() {
     for (auto& b : kvh) { s = s * 1664525u + 1013904223u; b = (unsigned char)(s >> 24); }
     CK(hipMalloc(&c.kv, kvh.size() + (1u << 16))); CK(hipMemcpy(c.kv, kvh.data(), kvh.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&c.sink, 64));
+    CK(hipMalloc(&c.stamps, 16 * 8 * 1024));
     printf("energy_probe: %d workgroups x %d threads (two waves per SIMD), random e4m3 operands; ns per iteration = launch time / iterations at the settled clock\n", c.grid, kThreads);
     const double m8 = run<0, 0, 0, 0, false, true>(c, "8 products only (bare MFMA)", 0);
     run<1, 0, 0, 0, false, true>(c, "+ row-sum MFMA (FAST's matrix work)", m8);
@@ -218,6 +229,9 @@ int main() {
     run<1, 75, 16, 2, true, true>(c, "everything, FAST's mix (no N_eff, ~100 VALU)", base);
     run<2, 62, 16, 2, true, true>(c, "everything with -25 % VALU", base);
     run<2, 83, 8, 2, true, true>(c, "everything with 8 ds_read_b128 (-50 %)", base);
+    run<2, 56, 18, 2, true, true>(c, "the kernel's ISA counts: ~90 VALU, 18 reads", base);
+    run<1, 50, 18, 2, true, true>(c, "FAST's ISA counts: ~82 VALU, 18 reads, no N_eff", base);
+    run<0, 56, 18, 2, true, false>(c, "everything BUT the matrix work (~90 VALU)", 0);
     run<0, 83, 0, 0, false, false>(c, "111 VALU alone (no matrix work)", 0);
     run<0, 0, 16, 0, false, false>(c, "16 ds_read_b128 alone", 0);
     return 0;

@@ -1,6 +1,6 @@
 // Bring-up probe for gfx950 FP8 MFMA (32x32x64 f8f6f4): operand/accumulator lane maps,
 // scaled vs unscaled semantics, issue rates, fp8 conversion behaviour.
-// Build: hipcc --offload-arch=gfx950 -O3 -o mfma_probe tools/mfma_probe.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o mfma_probe tools/probes/mfma_probe.hip
 // Test infrastructure only (not part of the product path).
 #include <hip/hip_runtime.h>
 #include <cstdio>

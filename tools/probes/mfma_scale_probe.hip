@@ -1,7 +1,7 @@
 // Development probe: how v_mfma_scale_f32_32x32x64_f8f6f4 takes its E8M0 block scales (groundwork for a block-scaled V).
 // A = B = 1.0 (e4m3 0x38) everywhere, so D[i][j] = sum over the two 32-wide K blocks of 32 * 2^(sa(i, blk) - 127) * 2^(sb(j, blk) - 127).
 // Lane l of A holds row l & 31, K block l >> 5 (32 fp8 values); the scale operand is one VGPR per lane, op_sel picks the byte.
-//   hipcc --offload-arch=gfx950 -O3 tools/mfma_scale_probe.hip -o tools/bin/mfma_scale_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_scale_probe.hip -o /tmp/mfma_scale_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef int v8i __attribute__((ext_vector_type(8)));

@@ -1,9 +1,9 @@
-"""Development: attention-only time of the D=128 head-wise kernel, auto vs fast, flat and peaked inputs (dev library)."""
+"""Development: attention-only time of the D=128 head-wise kernel, auto vs fast, flat and peaked inputs (product library; QLIB=<path>: another build)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from quantumattention_amd import _native
-if os.environ.get("USE_DEV", "1") == "1": _native.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab_libs", "libqattn_dev.so")
+if os.environ.get("QLIB"): _native.LIB_PATH = os.path.abspath(os.environ["QLIB"])
 B, H, S, D = 4, 32, 4096, 128
 torch.manual_seed(0)
 def timeit(fn, n=30):

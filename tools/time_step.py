@@ -1,10 +1,9 @@
-"""Development: time the fused step and the attention kernel alone (dev library; switches via QATTN_* env)."""
+"""Development: time the fused step and the attention kernel alone (product library; QLIB=<path>: another build, e.g. a tools/ab_libs variant)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from quantumattention_amd import _native
 if os.environ.get("QLIB"): _native.LIB_PATH = os.path.abspath(os.environ["QLIB"])
-elif os.environ.get("USE_DEV", "1") == "1": _native.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab_libs", "libqattn_dev.so")
 import quantumattention_amd as qa
 B, H, S, D = 4, 32, 4096, 128
 causal = "--causal" in sys.argv
