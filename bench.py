@@ -198,7 +198,14 @@ def step_with_path(_native, q, k, v, causal, fp8, precision):
     return _native.fp8_quant_attention_forward(q, k, v, is_causal=causal, precision=precision, fp8_dtype=_native.FP8_DTYPE[fp8], return_path=True)
 
 
-def accuracy_of_step(torch, _native, q, k, v, out, path, causal, fp8, rows, head=0, batch=0):
+def step_with_path_and_lse(_native, q, k, v, causal, fp8, precision):
+    """(out, lse fp32 [B,H,S], path): the per-row log-sum-exp vector written by the SAME launch as the output (the vector the reference defines,
+    tk/attention.py:333-346) together with the row paths."""
+    return _native.fp8_quant_attention_forward(q, k, v, is_causal=causal, precision=precision, fp8_dtype=_native.FP8_DTYPE[fp8], return_lse=True,
+                                               return_path=True)
+
+
+def accuracy_of_step(torch, _native, q, k, v, out, path, causal, fp8, rows, head=0, batch=0, lse=None):
     """max-abs / rmse of out[batch, head, rows] against fp64 SDPA (torch, on the GPU) of the library's own quantised q, k of that head with
       * `oracle`: per ROW the V of the path the kernel reports for the row (`path`, the row_path output of the same call): block-scaled
         fp8 V (block_scaled_v above) for QATTN_PATH_ONE_TERM / _TWO_TERM rows, the original 16-bit V for QATTN_PATH_V16 rows (query blocks
@@ -206,7 +213,9 @@ def accuracy_of_step(torch, _native, q, k, v, out, path, causal, fp8, rows, head
         ONE reference per row -- no "closer of two".  This is the parity number of BASELINE.json's north_star; bound per ELEMENT:
         2^-6 max(1, |O_ij| / 2) on fp8-V rows (plain 2^-6 wherever |O| <= 2: every BASELINE config), 2^-7 max(1, |O_ij|) on 16-bit-V rows;
         `worst_err_over_bound` < 1 <=> `within_bound`;
-      * `16bitV`: the original 16-bit V everywhere -- the distance to what the reference's kernel computes (it never quantises V)."""
+      * `16bitV`: the original 16-bit V everywhere -- the distance to what the reference's kernel computes (it never quantises V);
+      * lse (optional, the vector of the same launch): `lse_max_abs_err_one_term_rows` (stated tolerance 2.5e-2: sums of e4m3-rounded weights)
+        and `lse_max_abs_err_other_rows` (2e-3) against ln sum exp of the fp64 scores."""
     fp8_dtype = _native.FP8_DTYPE[fp8]
     D = q.shape[-1]
     S = q.shape[2]
@@ -237,6 +246,13 @@ def accuracy_of_step(torch, _native, q, k, v, out, path, causal, fp8, rows, head
         oref = torch.where(on16, o16, ob)
         bound = torch.where(on16, 2.0 ** -7 * oref.abs().clamp_min(1.0), 2.0 ** -6 * (oref.abs() / 2).clamp_min(1.0))
         d16, dor = (got[r0:r1] - o16).abs(), (got[r0:r1] - oref).abs()
+        if lse is not None:
+            dl = (lse[batch, head, r0:r1].double() - torch.logsumexp(sc, dim=1)).abs()
+            one = pth[r0:r1] == 0
+            if bool(one.any()):
+                worst["lse_max_abs_err_one_term_rows"] = max(worst.get("lse_max_abs_err_one_term_rows", 0.0), float(dl[one].max()))
+            if bool((~one).any()):
+                worst["lse_max_abs_err_other_rows"] = max(worst.get("lse_max_abs_err_other_rows", 0.0), float(dl[~one].max()))
         worst["max_abs_vs_16bitV"] = max(worst["max_abs_vs_16bitV"], float(d16.max()))
         worst["max_abs_vs_oracle"] = max(worst["max_abs_vs_oracle"], float(dor.max()))
         worst["worst_err_over_bound"] = max(worst["worst_err_over_bound"], float((dor / bound).max()))
@@ -656,18 +672,18 @@ def run_rank(args):
                 # distance to the reference's own semantics (V and P stay 16-bit there), per config, on a head slice
                 acc = {}
                 with qa.config.patch({"attention.fp8_format": "e4m3", "attention.precision": args.precision}):
-                    (o2, p2), (o3, p3) = step_with_path(_native, q, k, v, False, "e4m3", args.precision), step_with_path(_native, q, k, v, True, "e4m3", args.precision)
-                    # (the timed step is this call with row_path = NULL: same bits)
-                    acc["row_path_changes_nothing"] = bool(torch.equal(o2, qa.fp8_attn_func(q, k, v, is_causal=False)) and
+                    (o2, l2, p2), (o3, l3, p3) = step_with_path_and_lse(_native, q, k, v, False, "e4m3", args.precision), step_with_path_and_lse(_native, q, k, v, True, "e4m3", args.precision)
+                    # (the timed step is this call with lse = row_path = NULL: same bits)
+                    acc["lse_and_row_path_change_nothing"] = bool(torch.equal(o2, qa.fp8_attn_func(q, k, v, is_causal=False)) and
                                                            torch.equal(o3, qa.fp8_attn_func(q, k, v, is_causal=True)))
-                    acc["c2"] = accuracy_of_step(torch, _native, q, k, v, o2, p2, False, "e4m3", [0, 3072])
-                    acc["c3"] = accuracy_of_step(torch, _native, q, k, v, o3, p3, True, "e4m3", [0, 1024, 3072])
+                    acc["c2"] = accuracy_of_step(torch, _native, q, k, v, o2, p2, False, "e4m3", [0, 3072], lse=l2)
+                    acc["c3"] = accuracy_of_step(torch, _native, q, k, v, o3, p3, True, "e4m3", [0, 1024, 3072], lse=l3)
                     # a second slice per config: the last batch element's last head
                     acc["c2_last"] = accuracy_of_step(torch, _native, q, k, v, o2, p2, False, "e4m3", [1024, 3072], head=H - 1, batch=B - 1)
                     acc["c3_last"] = accuracy_of_step(torch, _native, q, k, v, o3, p3, True, "e4m3", [0, 2048, 3072], head=H - 1, batch=B - 1)
                     acc["c2_rows_by_path_whole_batch"] = [float((p2 == c).float().mean()) for c in range(3)]
                     acc["c3_rows_by_path_whole_batch"] = [float((p3 == c).float().mean()) for c in range(3)]
-                    del o2, o3, p2, p3
+                    del o2, o3, p2, p3, l2, l3
                 qx, kx, vx = (torch.randn(1, 2, 16384, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
                 o5, p5 = step_with_path(_native, qx, kx, vx, True, "e5m2", args.precision)
                 acc["c5_shape_B1_H2"] = accuracy_of_step(torch, _native, qx, kx, vx, o5, p5, True, "e5m2", [0, 8192, 15360])

@@ -8,7 +8,7 @@
 //     NV VALU instructions in the kernel's mix (per 32 scores: 16 v_pk_fma_f32, 16 v_cvt_pknorm_u16_f32, 8 v_perm_b32, 12 v_max3_f32,
 //        32 v_mov_b32 (accumulator zeroing), the rest v_add_f32 / v_mul_f32)
 //     NL ds_read_b128 (operand fragments: conflict-free 16-byte reads), ND global_load_lds_dwordx4 (K/V ring: 1 KiB per wave each, L2-resident source)
-//     a workgroup barrier + vmcnt(0) every second iteration when BAR
+//     a workgroup barrier + vmcnt(0) every second (EVERY-th) iteration when BAR
 // Test infrastructure only; nothing here is linked into the product.  Build + run on the GPU box:
 //     hipcc --offload-arch=gfx950 -O3 tools/probes/energy_probe.hip -o /tmp/energy_probe && /tmp/energy_probe
 #include <hip/hip_runtime.h>
@@ -66,7 +66,7 @@ __device__ __forceinline__ void valu_block(float (&x)[32], unsigned (&r)[8], flo
     }
 }
 
-template <int NSUM, int NV, int NL, int ND, bool BAR, bool MFMA>
+template <int NSUM, int NV, int NL, int ND, bool BAR, bool MFMA, int EVERY = 2>
 __global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsigned char* kv, float* sink, int iters, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsig
     frag[0] = v4i{0, 0, 0, 0}; frag[1] = frag[0];
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
-        if (BAR && (it & 1) == 0) {
+        if (BAR && (it & (EVERY - 1)) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -161,9 +161,9 @@ __global__ __launch_bounds__(kThreads) void k_energy(const v8i* ops, const unsig
 
 struct Ctx { v8i* ops; unsigned char* kv; float* sink; int grid; unsigned long long* stamps; };
 
-template <int NSUM, int NV, int NL, int ND, bool BAR, bool MFMA>
+template <int NSUM, int NV, int NL, int ND, bool BAR, bool MFMA, int EVERY = 2>
 static double run(const Ctx& c, const char* name, double base_ns) {
-    auto kern = k_energy<NSUM, NV, NL, ND, BAR, MFMA>;
+    auto kern = k_energy<NSUM, NV, NL, ND, BAR, MFMA, EVERY>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     const int iters = 6000;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -231,6 +231,9 @@ int main() {
     run<2, 83, 8, 2, true, true>(c, "everything with 8 ds_read_b128 (-50 %)", base);
     run<2, 56, 18, 2, true, true>(c, "the kernel's ISA counts: ~90 VALU, 18 reads", base);
     run<1, 50, 18, 2, true, true>(c, "FAST's ISA counts: ~82 VALU, 18 reads, no N_eff", base);
+    run<2, 56, 18, 2, true, true, 4>(c, "the kernel's ISA counts, barrier every 4 iterations", base);
+    run<2, 56, 18, 2, true, true, 1>(c, "the kernel's ISA counts, barrier every iteration", base);
+    run<2, 56, 18, 2, false, true>(c, "the kernel's ISA counts, no barrier", base);
     run<0, 56, 18, 2, true, false>(c, "everything BUT the matrix work (~90 VALU)", 0);
     run<0, 83, 0, 0, false, false>(c, "111 VALU alone (no matrix work)", 0);
     run<0, 0, 16, 0, false, false>(c, "16 ds_read_b128 alone", 0);
