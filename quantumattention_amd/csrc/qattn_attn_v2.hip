@@ -694,7 +694,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
         const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
         store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq && keep);
         if (p.lse && hh == 0 && qrow < p.Sq && keep)
-            p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot)) * p.lse_mul;
+            p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot) - (BYTE ? kByteLseBias : 0.0f)) * p.lse_mul;
         draw_finish(p, mail, tid_draw, ticket);
         static_assert(NW <= 8, "eight vote words");
         // (bytes 40 .. 47 behind the vote words and the mailbox: one per wave, "a flagged row of mine is severely peaked" -- kPeakR16)
@@ -731,7 +731,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
         if (p.lse && hh == 0) {
             // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l'); QATTN_LSE_REFERENCE: the reference's (disabled) vector
             // -(ln l + m ln2) sqrt(D) in rows padded to 16 bytes (tk/attention.py:333-346, 439-446)
-            const float lse = 0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot);
+            const float lse = 0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot) - (BYTE ? kByteLseBias : 0.0f);
             p.lse[bh * p.lse_stride + qrow] = lse * p.lse_mul;
         }
         if (TWO && p.path && hh == 0) p.path[bh * p.Sq + qrow] = (unsigned char)QATTN_PATH_TWO_TERM;   // (one-term sweeps leave the call's pre-fill)
@@ -1048,7 +1048,10 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
         // unit variance (or no estimate): the key-count rule; a head that IS wide: two-term when so many rows are expected to end peaked
         // that gathering and recomputing them would cost more than the two-term sweep
         const bool wide = var >= kVarDeadband;
-        const bool start_two = predicted_r((float)nkeys, 1.0f, p.peak_z) < kPeakR0 || (wide && many_rows_peaked((float)nkeys, var));
+        // (the key-count rule as the integer comparison it stands for: predicted_r(nkeys, 1, peak_z) < kPeakR0 <=> nkeys < two_term_keys
+        // up to float rounding -- which at nkeys == two_term_keys EXACTLY, a non-causal call with 1024 keys, fell on the wrong side and
+        // started every block on the precise pass, FAST included: found by the strict per-row-path grader, tools/fuzz_parity.py seed 182 #191)
+        const bool start_two = nkeys < p.two_term_keys || (wide && many_rows_peaked((float)nkeys, var));
         two = __builtin_amdgcn_readfirstlane(start_two ? 1 : 0) != 0;   // (every lane holds the same value)
     }
     unsigned to_rescue = 0u;

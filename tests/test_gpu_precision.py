@@ -425,3 +425,24 @@ def test_heavy_tailed_value_row_meets_the_scaled_bound_and_accurate_meets_the_fl
     assert TOL < mx < TOL * 60.0 / 4.5, mx
     acc, p_acc = _run(q, k, v, False, "accurate")
     assert_within_bound(acc, ref, p_acc)
+
+
+@pytest.mark.parametrize("Skv", [1023, 1024, 1025])
+def test_key_count_rule_is_exact_at_the_1024_key_boundary(Skv):
+    """Found by the strict grader (tools/fuzz_parity.py seed 182 case 191): a query block is "early" -- every mode attends the 16-bit V -- when
+    its first row sees FEWER than 1024 keys.  The kernel tested predicted_r(nkeys, 1, peak_z) < 24 in floating point, which at nkeys = 1024
+    exactly rounded to the wrong side: a non-causal call with 1024 keys ran every block on the precise pass, `fast` included (correct
+    results, wrong path).  Now an integer comparison: 1023 keys -> V16 everywhere, 1024 / 1025 -> `fast` stays on the one-term sweep."""
+    torch.manual_seed(Skv)
+    q = torch.randn(1, 2, 512, 128, dtype=torch.bfloat16)
+    k, v = (torch.randn(1, 2, Skv, 128, dtype=torch.bfloat16) for _ in range(2))
+    ref = _oracle(q, k, v, False)
+    for precision in ("fast", "auto"):
+        got, path = _run(q, k, v, False, precision)      # (check_path_structure inside asserts the rule for `fast`)
+        assert_within_bound(got, ref, path, what=(Skv, precision))
+        if Skv < 1024:
+            assert (path == PATH_V16).all()
+        elif precision == "fast":
+            assert (path == PATH_ONE_TERM).all()
+        else:
+            assert (path == PATH_ONE_TERM).mean() > 0.9
