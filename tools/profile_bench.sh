@@ -12,7 +12,7 @@ mkdir -p $OUT
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.csrc_sha16())" > $OUT/csrc_sha16.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 STEPS=${PROF_STEPS:-20}
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras $*"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras --no-live-traffic $*"
 # PROF_SCRIPT=1: profile tools/trace_step.py instead (MODE / SHAPE / CAUSAL / PREC from the environment: the token-wise and 16-bit
 # paths, which bench.py does not drive); its STEPS stand in for --steps
 if [ "${PROF_SCRIPT:-0}" = "1" ]; then
