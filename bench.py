@@ -270,7 +270,7 @@ def accuracy_of_step(torch, _native, q, k, v, out, path, causal, fp8, rows, head
         `worst_err_over_bound` < 1 <=> `within_bound`;
       * `16bitV`: the original 16-bit V everywhere -- the distance to what the reference's kernel computes (it never quantises V);
       * lse (optional, the vector of the same launch): `lse_max_abs_err_one_term_rows` (stated tolerance 2e-2: sums of e4m3-rounded weights, mean offset removed)
-        and `lse_max_abs_err_other_rows` (2e-3) against ln sum exp of the fp64 scores."""
+        and `lse_max_abs_err_other_rows` (2e-3; 16-bit-V rows 4e-3) against ln sum exp of the fp64 scores."""
     fp8_dtype = _native.FP8_DTYPE[fp8]
     D = q.shape[-1]
     S = q.shape[2]

@@ -143,7 +143,7 @@ int qattn_fp8_quant_attention_forward(const void* q, const void* k, const void* 
  *       sums of x^2, both or neither) come along; without them wide heads start one-term (same bound).  Too large is safe, too small clips.
  *   lse / lse_layout  NULL or the per-row log-sum-exp written BY THE SAME LAUNCH as `out` (reference: l_vec, tk/attention.py:79,85,333-346,
  *       439-452).  D = 128 head-wise FP8 sweep: from the sum of the e4m3-rounded weights the second GEMM consumed (mean offset removed), `out`
- *       unchanged, within 2e-2 (natural-log units); every other row within 2e-3.
+ *       unchanged, within 2e-2 (natural log); 16-bit-V rows (sums of the rounded P) 4e-3, others 2e-3.
  *   row_path  NULL or uint8 [B,Hq,Sq] (QATTN_PATH_*): test / debug output; no cost when NULL, `out` does not depend on it.
  */
 int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k, const void* v, int in_fmt, void* out, void* q8, void* k8,

@@ -171,8 +171,8 @@ def test_fused_path_from_16bit_inputs(case):
     # LSE from the fused call, every row (the per-row vector the reference defines, tk/attention.py:333-346, 439-446).  Stated tolerance
     # (include/qattn.h): rows of the FP8-MFMA sweep carry the sum of the e4m3-ROUNDED weights the second GEMM consumed (their mean offset,
     # +0.01353, is subtracted by the epilogue: csrc/qattn_attn.h kByteLseBias): 2e-2; every other row (exact exponentials, 16-bit or fp32
-    # sums) 2e-3.
-    lse_tol = np.where(path == PATH_ONE_TERM, 2e-2 if d128_head else 2e-3, 2e-3)
+    # sums) 2e-3, 16-bit-V rows 4e-3 (sums of the ROUNDED 16-bit P: bf16's 2^-8 undiluted on a row carried by one key).
+    lse_tol = np.where(path == PATH_ONE_TERM, 2e-2 if d128_head else 2e-3, np.where(path == PATH_V16, 4e-3, 2e-3))
     assert (np.abs(lse_f - ref_lse) < lse_tol).all(), float(np.abs(lse_f - ref_lse).max())
     # optional LSE output of the separate calls (exact-exponential path)
     qg8, sqg = _native.quant_fp8(q.cuda(), scaling=scaling, fp8_dtype=TDT[fp8])

@@ -446,3 +446,27 @@ def test_key_count_rule_is_exact_at_the_1024_key_boundary(Skv):
             assert (path == PATH_ONE_TERM).all()
         else:
             assert (path == PATH_ONE_TERM).mean() > 0.9
+
+
+@pytest.mark.parametrize("sharp,causal", [(1.3, False), (1.3, True), (3.0, False), ("mixed", True)])
+def test_lse_of_the_same_launch_on_rescued_and_16bit_v_rows(sharp, causal):
+    """The fused entry's LSE (ABI 7) is written by whichever pass stores the row: the FP8 sweep's epilogue (sums of e4m3-rounded weights,
+    mean offset removed: 2e-2), the two-term rescue (exact fp32 sums: 2e-3), the 16-bit-V rescue and block pass (sums of the rounded 16-bit P: 4e-3).  Peaked
+    inputs put rows on every one of them; every row's entry is held to the tolerance of ITS path, and the output is the plain call's."""
+    S, D = 4096 if not causal else 2304, 128
+    q, k, v = _inputs(S, D, sharp, seed=S + 11)
+    q8, sq = oracle.quantize_fp8(bits16(q), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    k8, sk = oracle.quantize_fp8(bits16(k), oracle.FMT_BF16, "head", oracle.FMT_E4M3)
+    ref, ref_lse = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, causal=causal, v_block=True, return_lse=True)
+    got, path, lse = fused_call(q, k, v, causal=causal, return_lse=True)
+    plain, path2 = _run(q, k, v, causal, "auto")
+    np.testing.assert_array_equal(got, plain)
+    np.testing.assert_array_equal(path, path2)
+    assert_within_bound(got, ref, path)
+    err = np.abs(lse - ref_lse)
+    # (16-bit-V rows sum the ROUNDED 16-bit P, as the reference kernel's l_vec would: on a row carried by one or two keys that is bf16's
+    # 2^-8 relative rounding undiluted -- 4e-3; rows of the two-term rescue sum the exact fp32 exponentials: 2e-3)
+    tol = np.where(path == PATH_ONE_TERM, 2e-2, np.where(path == PATH_V16, 4e-3, 2e-3))
+    assert (err < tol).all(), {int(c): float(err[path == c].max()) for c in np.unique(path)}
+    if sharp != 1.3 or causal:
+        assert (path != PATH_ONE_TERM).any()
