@@ -709,6 +709,26 @@ def run_rank(args):
                 line["c5_causal_e5m2_B4_H40_S16384"] = extra(4, 40, 16384, True, "e5m2", 5)
                 # the reference's second scaling mode (fp8_token_wise_attn_func, quantum_attn_interface.py:179-202) at the C2 / C3 shape: per-row
                 # scales of q and k, on the templated kernel (csrc/qattn_attn_v4.hip)
+                # the form attention inputs usually arrive in: q, k, v = transposed views of [B,S,H,D] projection outputs.  The kernels take the
+                # strides (include/qattn_strided.h): `views` = the step on the views as they are, `copies` = the same step behind three
+                # `.contiguous()` copies (what a dense-only entry costs such a caller; the reference copies v: tk/attention.py:419-421)
+                try:
+                    xs = [torch.randn(4, 4096, 32, D, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+                    qv, kv, vv = (x.transpose(1, 2) for x in xs)
+                    with qa.config.patch({"attention.fp8_format": "e4m3", "attention.precision": args.precision}):
+                        ms_v = event_time(lambda: qa.fp8_attn_func(qv, kv, vv, is_causal=False), 20)
+                        ams_v = attn_in_step(lambda: qa.fp8_attn_func(qv, kv, vv, is_causal=False), 10)
+                        ms_c = event_time(lambda: qa.fp8_attn_func(qv.contiguous(), kv.contiguous(), vv.contiguous(), is_causal=False), 20)
+                        same = bool(torch.equal(qa.fp8_attn_func(qv, kv, vv, is_causal=False),
+                                                qa.fp8_attn_func(qv.contiguous(), kv.contiguous(), vv.contiguous(), is_causal=False)))
+                    fl = flops(4, 32, 4096, 4096, D, False)
+                    line["c2_strided_views"] = {"layout": "q, k, v = x.transpose(1, 2) of [B,S,H,D] bf16 tensors (C2 shape)", "ms_per_step_views": ms_v,
+                                                "attn_kernel_ms_views": ams_v, "step_TFLOPs_views": fl / (ms_v * 1e-3) / 1e12,
+                                                "ms_per_step_copies": ms_c, "step_TFLOPs_copies": fl / (ms_c * 1e-3) / 1e12,
+                                                "views_equal_copies_bit_for_bit": same}
+                    del xs, qv, kv, vv
+                except Exception as exc:
+                    print(f"[bench] strided-view sample skipped: {exc}", file=sys.stderr)
                 line["c2_token_wise"] = extra(4, 32, 4096, False, "e4m3", 20, token_wise=True)
                 line["c3_token_wise"] = extra(4, 32, 4096, True, "e4m3", 20, token_wise=True)
                 # the reference's own benchmark grid (tests/test_interface.py:95-102,141-156): B16 H16 S8192, D in {64,128,256}

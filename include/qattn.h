@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define QATTN_ABI_VERSION 7   /* 7 (round 6): lse / lse_layout / row_path on ..._forward_ex, ..._forward_rowmajor, qattn_describe_path */
+#define QATTN_ABI_VERSION 8   /* 7: lse / row_path on ..._forward_ex, ..._rowmajor, qattn_describe_path; 8: qattn_strided.h */
 
 #define QATTN_FMT_E4M3 0 /* OCP float8_e4m3fn (torch.float8_e4m3fn) */
 #define QATTN_FMT_E5M2 1 /* OCP float8_e5m2   (torch.float8_e5m2)   */
@@ -203,7 +203,7 @@ int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, 
         int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, int fast_exp,
         void* stream);
 
-/* measurement aids (clock stamps, launch timing, bare-MFMA probe): include/qattn_measure.h */
+/* strided views of q, k, v: qattn_strided.h; measurement aids (clock stamps, launch timing, probe): qattn_measure.h */
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ FMT_E4M3, FMT_E5M2, FMT_BF16, FMT_FP16 = 0, 1, 2, 3
 SCALE_HEAD, SCALE_TOKEN = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_KFRAG, LAYOUT_VFRAG, LAYOUT_K16FRAG, LAYOUT_V16FRAG = 0, 1, 2, 3, 4
 NUMERICS = {"compiled": 0, "eager": 1}
-ABI_VERSION = 7
+ABI_VERSION = 8
 PRECISION = {"auto": 0, "fast": 1, "accurate": 2}
 LSE_NATURAL, LSE_REFERENCE = 0, 1
 PATH_ONE_TERM, PATH_TWO_TERM, PATH_V16 = 0, 1, 2   # QATTN_PATH_*: the fused entry's per-row debug output
@@ -36,6 +36,7 @@ EXPORTS = (
     "qattn_profile_attention", "qattn_last_attention_ms", "qattn_vblock_exponent", "qattn_fp8_quant_attention_forward_ex",
     "qattn_attention_stamp_bytes", "qattn_fp8_quant_attention_forward_stamped", "qattn_mfma_probe_bytes", "qattn_mfma_probe",
     "qattn_fp8_attention_rowmajor_workspace_bytes", "qattn_fp8_attention_forward_rowmajor", "qattn_describe_path",
+    "qattn_fp8_quant_attention_forward_strided", "qattn_pack16_strided", "qattn_attention_forward_16_strided",
 )
 
 
@@ -113,6 +114,13 @@ def lib() -> ctypes.CDLL:
     L.qattn_fp8_quant_attention_forward_ex.restype = i
     L.qattn_fp8_quant_attention_forward_ex.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                                        i, i, i, i, i, i, i, i, i, i, f, i, vp, i, vp, vp, sz, vp]
+    L.qattn_pack16_strided.restype = i
+    L.qattn_pack16_strided.argtypes = [vp, vp, vp, i, i, i, i, i, vp]
+    L.qattn_attention_forward_16_strided.restype = i
+    L.qattn_attention_forward_16_strided.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, vp]
+    L.qattn_fp8_quant_attention_forward_strided.restype = i
+    L.qattn_fp8_quant_attention_forward_strided.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                            i, i, i, i, i, i, i, i, i, i, f, i, vp, i, vp, vp, sz, vp]
     L.qattn_attention_stamp_bytes.restype = sz
     L.qattn_attention_stamp_bytes.argtypes = [i, i, i]
     L.qattn_fp8_quant_attention_forward_stamped.restype = i
@@ -171,6 +179,25 @@ def _check_qkv(q, k, v):
     Hkv, Skv = k.shape[1], k.shape[2]
     _require(Hkv > 0 and Hq % Hkv == 0, f"Hq={Hq} is not a multiple of Hkv={Hkv}")
     return B, Hq, Hkv, Sq, Skv, D
+
+
+def _strided_ok(t: torch.Tensor) -> bool:
+    """A 4-D view the kernels address directly (include/qattn_strided.h): head_dim innermost and dense, every other stride a non-negative
+    multiple of 8 elements (rows 16-byte aligned), rows at most 2^23 elements apart, base 16-byte aligned."""
+    if t.is_contiguous():
+        return True
+    D = t.shape[3]
+    return (t.stride(3) == 1 and all(t.shape[i] == 1 or (t.stride(i) >= 0 and t.stride(i) % 8 == 0) for i in (0, 1, 2))
+            and (t.shape[2] == 1 or D <= t.stride(2) <= 2 ** 23) and t.data_ptr() % 16 == 0)
+
+
+def _strides3(t: torch.Tensor):
+    """{batch, head, row} element strides of a view `_strided_ok` accepted, as the C entries take them (None: dense)."""
+    if t.is_contiguous():
+        return None
+    H, S, D = t.shape[1], t.shape[2], t.shape[3]
+    dense = (H * S * D, S * D, D)     # (a dimension of size 1 has no stride of its own)
+    return (ctypes.c_longlong * 3)(*[t.stride(i) if t.shape[i] > 1 else dense[i] for i in (0, 1, 2)])
 
 
 def _check_scales(scale_q, scale_k, scale_v, mode, B, Hq, Hkv, Sq, Skv, device) -> None:
@@ -352,13 +379,13 @@ def fp8_attention_forward_rowmajor(q8: torch.Tensor, k8: torch.Tensor, v16: torc
 def pack16(x: torch.Tensor, layout: int) -> torch.Tensor:
     """row-major bf16/fp16 [B,H,S,D] -> flat uint8 buffer in K16FRAG / V16FRAG layout."""
     _require(x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16), "pack16 needs a 4-D bf16/fp16 device tensor")
-    x = x.contiguous()
+    x = x if _strided_ok(x) else x.contiguous()     # (a strided view with head_dim innermost is read as it is: include/qattn_strided.h)
     B, H, S, D = x.shape
     L = lib()
     with torch.cuda.device(x.device):
         out = torch.empty((L.qattn_16bit_tensor_bytes(layout, B, H, S, D),), dtype=torch.uint8, device=x.device)
-        rc = L.qattn_pack16(x.data_ptr(), out.data_ptr(), B, H, S, D, layout, _stream(x))
-    _check(rc, "qattn_pack16")
+        rc = L.qattn_pack16_strided(x.data_ptr(), _strides3(x), out.data_ptr(), B, H, S, D, layout, _stream(x))
+    _check(rc, "qattn_pack16_strided")
     return out
 
 
@@ -366,19 +393,19 @@ def attention_forward_16(q: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Te
                          is_causal: bool, sm_scale: float = 0.0, return_lse: bool = False, fast_exp: bool = False):
     """q: row-major bf16/fp16 [B,Hq,Sq,D]; k_frag / v_frag: K16FRAG / V16FRAG buffers for [B,Hkv,Skv,D]."""
     _require(q.is_cuda and q.dim() == 4, "attention_forward_16 needs a 4-D device query")
-    q = q.contiguous()
+    q = q if _strided_ok(q) else q.contiguous()
     B, Hq, Sq, D = q.shape
     L = lib()
     _require(k_frag.numel() * k_frag.element_size() >= L.qattn_16bit_tensor_bytes(LAYOUT_K16FRAG, B, Hkv, Skv, D)
              and v_frag.numel() * v_frag.element_size() >= L.qattn_16bit_tensor_bytes(LAYOUT_V16FRAG, B, Hkv, Skv, D),
              "k_frag / v_frag are smaller than the fragment layouts of [B,Hkv,Skv,D]")
     with torch.cuda.device(q.device):
-        out = torch.empty_like(q)
+        out = torch.empty((B, Hq, Sq, D), dtype=q.dtype, device=q.device)   # dense, whatever the strides of q
         lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if return_lse else None
-        rc = L.qattn_attention_forward_16(q.data_ptr(), k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
-                                          B, Hq, Hkv, Sq, Skv, D, fmt_of(q.dtype), int(is_causal), float(sm_scale),
-                                          int(fast_exp), _stream(q))
-    _check(rc, "qattn_attention_forward_16")
+        rc = L.qattn_attention_forward_16_strided(q.data_ptr(), _strides3(q), k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
+                                                  B, Hq, Hkv, Sq, Skv, D, fmt_of(q.dtype), int(is_causal), float(sm_scale),
+                                                  int(fast_exp), _stream(q))
+    _check(rc, "qattn_attention_forward_16_strided")
     return (out, lse) if return_lse else out
 
 
@@ -404,7 +431,13 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
     launch as the output.  return_path: also the uint8 [B,Hq,Sq] PATH_* code of every row (test / debug output).
     Returns out, or (out, lse), (out, path), (out, lse, path)."""
     B, Hq, Hkv, Sq, Skv, D = _check_qkv(q, k, v)
-    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    # strided views (q = x.view(B, S, H, D).transpose(1, 2), slices of a packed QKV projection, ...) go to the kernels as they are
+    # (include/qattn_strided.h); only what the kernels cannot address -- a head_dim that is not innermost and dense, rows off 16 bytes -- is copied
+    q, k, v = (t if _strided_ok(t) else t.contiguous() for t in (q, k, v))
+    strides = None
+    if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        dense = lambda t: (t.shape[1] * t.shape[2] * D, t.shape[2] * D, D)     # (a dimension of size 1 has no stride of its own)
+        strides = (ctypes.c_longlong * 9)(*[t.stride(i) if t.shape[i] > 1 else dense(t)[i] for t in (q, k, v) for i in (0, 1, 2)])
     L = lib()
     mode = _scale_mode(scaling)
     dev = q.device
@@ -414,7 +447,7 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
     amax_q, ssq_q = _per_head("amax_q", amax_q, B, Hq, dev), _per_head("ssq_q", ssq_q, B, Hq, dev)
     amax_k, amax_v, ssq_k = (_per_head(n, t, B, Hkv, dev) for n, t in (("amax_k", amax_k), ("amax_v", amax_v), ("ssq_k", ssq_k)))
     with torch.cuda.device(dev):
-        out = torch.empty_like(q)
+        out = torch.empty((B, Hq, Sq, D), dtype=q.dtype, device=dev)   # dense, whatever the strides of q (tk/attention.py:434-437)
         q8 = torch.empty((B, Hq, Sq, D), dtype=torch.uint8, device=dev)
         kf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
         vf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
@@ -425,13 +458,13 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         lse = torch.empty((B, Hq, L.qattn_lse_row_stride(Sq, lse_layout)), dtype=torch.float32, device=dev) if return_lse else None
         path = torch.empty((B, Hq, Sq), dtype=torch.uint8, device=dev) if return_path else None
-        rc = L.qattn_fp8_quant_attention_forward_ex(
-            q.data_ptr(), k.data_ptr(), v.data_ptr(), fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
+        rc = L.qattn_fp8_quant_attention_forward_strided(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), strides, fmt_of(q.dtype), out.data_ptr(), q8.data_ptr(), kf.data_ptr(),
             vf.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), _ptr(amax_q), _ptr(amax_k), _ptr(amax_v), _ptr(ssq_q),
             _ptr(ssq_k), B, Hq, Hkv, Sq, Skv, D, fmt_of(fp8_dtype), mode,
             _numerics(numerics), int(is_causal), float(sm_scale), _precision(precision), _ptr(lse), lse_layout, _ptr(path),
             ws.data_ptr(), ws_bytes, _stream(q))
-    _check(rc, "qattn_fp8_quant_attention_forward_ex")
+    _check(rc, "qattn_fp8_quant_attention_forward_strided")
     if not (return_lse or return_path):
         return out
     return (out,) + ((lse[..., :Sq],) if return_lse else ()) + ((path,) if return_path else ())

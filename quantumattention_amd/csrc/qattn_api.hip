@@ -62,6 +62,8 @@ struct AttnCall {
     unsigned long long* stamps;   // measurement entry (else nullptr)
     bool sched_zeroed;            // fused step: the pre-pass has cleared the hand-out counters (else the launch clears them itself)
     unsigned char* path;          // fused entry's per-row path output (else nullptr)
+    const long long* q16_strides = nullptr;   // fused step: element strides {batch, head, row} of the 16-bit q / v views (nullptr: dense [B,H,S,D])
+    const long long* v16_strides = nullptr;
 };
 
 // attention workspace = [SchedState of the hand-scheduled kernel's causal launches | one flag word per (b, h, 32-row group)]
@@ -138,6 +140,11 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.stamp_buf = a.stamps;
     p.path = a.path;
     p.v16 = v_is_16 ? (const unsigned char*)a.v8 : (const unsigned char*)a.v16;
+    // byte strides of the 16-bit Q / V as the kernels read them (qattn_attn.h q16_row / v16_head): the caller's view, or dense
+    p.q16_rs = 2L * a.D; p.q16_hs = p.q16_rs * a.Sq; p.q16_bs = p.q16_hs * a.Hq;
+    p.v16_rs = 2L * a.D; p.v16_hs = p.v16_rs * a.Skv; p.v16_bs = p.v16_hs * a.Hkv;
+    if (a.q16 && a.q16_strides) { p.q16_bs = 2 * a.q16_strides[0]; p.q16_hs = 2 * a.q16_strides[1]; p.q16_rs = 2 * a.q16_strides[2]; }
+    if (!v_is_16 && a.v16 && a.v16_strides) { p.v16_bs = 2 * a.v16_strides[0]; p.v16_hs = 2 * a.v16_strides[1]; p.v16_rs = 2 * a.v16_strides[2]; }
     if (a.stamps && !(a.q16 && attn_v2_covers(a.D, a.is_causal, a.scale_mode) && a.qk_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
     const bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
     p.peak_z = (float)p.two_term_keys > kPeakR0 ? 0.5f + logf((float)p.two_term_keys / kPeakR0) : 0.0f;   // see predicted_r
@@ -302,8 +309,19 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                                 const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
                                 int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
                                 int precision, float* lse, int lse_layout, unsigned char* row_path, void* workspace, size_t workspace_bytes,
-                                void* stream, unsigned long long* stamps) {
+                                void* stream, unsigned long long* stamps, const long long* strides = nullptr) {
     if (!q || !k || !v || !out || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
+    if (strides) {
+        // strided views of the 16-bit inputs (qattn_fp8_quant_attention_forward_strided): D innermost and dense, every row 16-byte aligned,
+        // no two rows overlapping is the caller's business; 64 rows of a tensor within 2^31 bytes (32-bit lane offsets of the LDS-DMA requests)
+        const void* base[3] = {q, k, v};
+        for (int t = 0; t < 3; t++) {
+            if ((reinterpret_cast<uintptr_t>(base[t]) & 15u) != 0) return QATTN_ERR_INVALID_ARG;
+            for (int i = 0; i < 3; i++)
+                if (strides[3 * t + i] < 0 || strides[3 * t + i] % 8 != 0) return QATTN_ERR_INVALID_ARG;
+            if (strides[3 * t + 2] < D || strides[3 * t + 2] > (1LL << 23)) return QATTN_ERR_INVALID_ARG;
+        }
+    }
     if (lse_layout != QATTN_LSE_NATURAL && lse_layout != QATTN_LSE_REFERENCE) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
@@ -345,7 +363,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                               : precision == QATTN_PRECISION_AUTO ? attn_ws_sched_bytes(B, Hq, Sq) + attn_ws_flag_bytes(B, Hq, Sq) : 0;
     int rc = launch_quant_qkv(q, k, v, in_fmt, q8, k8, v8, scale_q, scale_k, scale_v, B, Hq, Hkv, Sq, Skv, D, fp8_fmt, scale_mode,
                               numerics, ws, fuse_q, moments, v_block, st, ext_amax, zero_in_prepass && zero_bytes ? (unsigned*)attn_ws : nullptr,
-                              zero_in_prepass ? (int)(zero_bytes / sizeof(unsigned)) : 0);
+                              zero_in_prepass ? (int)(zero_bytes / sizeof(unsigned)) : 0, strides);
     if (rc != QATTN_OK) return rc;
     if (row_path) {   // every row starts as "one-term fp8-V sweep"; the other passes overwrite what they store
         const long n = (long)B * Hq * Sq;
@@ -360,7 +378,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, v, stamps, zero_in_prepass, row_path};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, v, stamps, zero_in_prepass, row_path, strides, strides ? strides + 6 : nullptr};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }
@@ -375,6 +393,22 @@ extern "C" int qattn_fp8_quant_attention_forward_ex(const void* q, const void* k
     return quant_attention_impl(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, amax_q, amax_k, amax_v, ssq_q, ssq_k, B, Hq, Hkv,
                                 Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, lse, lse_layout, row_path, workspace,
                                 workspace_bytes, stream, nullptr);
+}
+
+// The fused entry on STRIDED VIEWS of the 16-bit inputs -- e.g. q = x.view(B, S, H, D).transpose(1, 2), the form attention inputs have in
+// most callers.  The reference reads such q / k in its Inductor-made quantiser and copies such a v (`.contiguous()`, tk/attention.py:419-421);
+// here every kernel that touches the 16-bit tensors (abs-max pass, quantise pass, the attention kernels' Q rows and 16-bit-V passes) takes
+// the strides, so nothing is copied and the result is the dense call's, bit for bit.
+extern "C" int qattn_fp8_quant_attention_forward_strided(const void* q, const void* k, const void* v, const long long* strides, int in_fmt, void* out,
+                                                         void* q8, void* k8, void* v8, float* scale_q, float* scale_k, float* scale_v,
+                                                         const float* amax_q, const float* amax_k, const float* amax_v,
+                                                         const float* ssq_q, const float* ssq_k, int B, int Hq, int Hkv, int Sq, int Skv,
+                                                         int D, int fp8_fmt, int scale_mode, int numerics, int is_causal, float sm_scale,
+                                                         int precision, float* lse, int lse_layout, unsigned char* row_path, void* workspace,
+                                                         size_t workspace_bytes, void* stream) {
+    return quant_attention_impl(q, k, v, in_fmt, out, q8, k8, v8, scale_q, scale_k, scale_v, amax_q, amax_k, amax_v, ssq_q, ssq_k, B, Hq, Hkv,
+                                Sq, Skv, D, fp8_fmt, scale_mode, numerics, is_causal, sm_scale, precision, lse, lse_layout, row_path, workspace,
+                                workspace_bytes, stream, nullptr, strides);
 }
 
 extern "C" size_t qattn_attention_stamp_bytes(int B, int Hq, int Sq) {

@@ -148,7 +148,20 @@ struct AttnParams {
     // rows, two-term blocks of the templated kernel) or QATTN_PATH_V16 (16-bit P on the caller's 16-bit V: early blocks, blocks on the
     // 16-bit-V pass, severely peaked rescued rows).  The one-term sweeps never touch it.
     unsigned char* path;
+    // The caller's 16-bit Q and V as the attention kernels read them (q16 / v16 above) may be STRIDED views of [B,H,S,D] -- D innermost and
+    // dense, e.g. the transposed view of a [B,S,H,D] projection output (the reference's launcher copies such a V: tk/attention.py:419-421).
+    // Byte strides of batch, head and row; dense: {H S D 2, S D 2, D 2}.  (attention_impl, qattn_api.hip)
+    long q16_bs, q16_hs, q16_rs;
+    long v16_bs, v16_hs, v16_rs;
 };
+
+// first byte of row `row` of head (b, h) of the 16-bit Q / of kv head (b, hkv) of the 16-bit V
+__device__ __forceinline__ const unsigned char* q16_row(const AttnParams& p, int b, int h, int row) {
+    return p.q16 + (long)b * p.q16_bs + (long)h * p.q16_hs + (long)row * p.q16_rs;
+}
+__device__ __forceinline__ const unsigned char* v16_head(const AttnParams& p, int b, int hkv) {
+    return p.v16 + (long)b * p.v16_bs + (long)hkv * p.v16_hs;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Block hand-out inside one persistent causal launch of the D = 128 kernel.  The only datum that travels between workgroups is

@@ -46,6 +46,7 @@ struct Attn16Params {
     int nqb, ntiles, xcd_remap;
     float sm_log2e;
     int fast_exp;  // opt-in linear-mantissa exponential for rows that see >= kTwoTermKeys keys
+    long q_bs, q_hs, q_rs;   // byte strides of q: batch, head, row (a strided view with D innermost; dense: Hq Sq D 2, Sq D 2, D 2)
 };
 
 constexpr int kWaves16 = 4;                        // 128 query rows per workgroup
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kWaves16 * 64, (D == 256 ? 2 : 3)) void attn16_fwd_
     vec16 qf[KS];
     {
         const bool qvalid = qrow < p.Sq;
-        const unsigned char* qp = p.q + ((((long)b * p.Hq + h) * p.Sq + (qvalid ? qrow : 0)) * D + hh * 8) * 2;
+        const unsigned char* qp = p.q + (long)b * p.q_bs + (long)h * p.q_hs + (long)(qvalid ? qrow : 0) * p.q_rs + hh * 16;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             v4i raw = *reinterpret_cast<const v4i*>(qp + s * 32);
@@ -289,12 +290,13 @@ __global__ __launch_bounds__(kWaves16 * 64, (D == 256 ? 2 : 3)) void attn16_fwd_
 
 // 16-bit row-major [G, S, D] -> K16FRAG / V16FRAG.  grid = (ceil(S/64), G), block = 256.
 template <int D, int LAYOUT>
-__global__ __launch_bounds__(256) void pack16_tile_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int S) {
+__global__ __launch_bounds__(256) void pack16_tile_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int S, int H, long sb, long sh,
+                                                          long ss) {   // sb, sh, ss: 16-byte vectors between batches, heads, rows of x
     constexpr int VPR = D / 8;            // 16-byte vectors (8 elements) per row
     constexpr int RSTRIDE = D * 2 + 4;    // V staging: row stride in bytes (breaks the power-of-two stride for the gather)
     __shared__ __attribute__((aligned(16))) unsigned char img[64 * RSTRIDE];
     const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, row0 = tile * 64;
-    const uint4* xg = x + (long)g * S * VPR;
+    const uint4* xg = x + (long)(g / H) * sb + (long)(g % H) * sh;
     const long Sp = (long)((S + 63) / 64) * 64;
     uint4* og = out + ((long)g * Sp + row0) * VPR;   // a chunk is 64*D*2 bytes = 64*VPR vectors
     if (LAYOUT == QATTN_LAYOUT_K16FRAG) {
@@ -303,14 +305,14 @@ __global__ __launch_bounds__(256) void pack16_tile_kernel(const uint4* __restric
             const int key = i & 31, hh2 = (i >> 5) & 1, s = (i >> 6) % (D / 16), t = i / (64 * (D / 16));
             const int row = row0 + 32 * t + key;
             uint4 raw = make_uint4(0, 0, 0, 0);
-            if (row < S) raw = xg[(long)row * VPR + 2 * s + hh2];
+            if (row < S) raw = xg[(long)row * ss + 2 * s + hh2];
             og[i] = raw;
         }
     } else {
         for (int vecn = tid; vecn < 64 * VPR; vecn += 256) {
             const int r = vecn / VPR, dv = vecn % VPR, row = row0 + r;
             uint4 raw = make_uint4(0, 0, 0, 0);
-            if (row < S) raw = xg[(long)row * VPR + dv];
+            if (row < S) raw = xg[(long)row * ss + dv];
             unsigned* dst = reinterpret_cast<unsigned*>(img + r * RSTRIDE + dv * 16);
             dst[0] = raw.x; dst[1] = raw.y; dst[2] = raw.z; dst[3] = raw.w;
         }
@@ -368,33 +370,53 @@ extern "C" size_t qattn_16bit_tensor_bytes(int layout, int B, int H, int S, int 
     return (size_t)B * H * Sp * D * 2;
 }
 
-extern "C" int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H, int S, int D, int out_layout, void* stream) {
-    if (!x_rowmajor || !x_packed || B <= 0 || H <= 0 || S <= 0) return QATTN_ERR_INVALID_ARG;
+// element strides {batch, head, row} of a 16-bit [B,H,S,D] view with D innermost and dense (include/qattn_strided.h); nullptr: dense
+static bool strides16_ok(const void* base, const long long* st, int D) {
+    if (!st) return true;
+    if ((reinterpret_cast<uintptr_t>(base) & 15u) != 0) return false;
+    for (int i = 0; i < 3; i++)
+        if (st[i] < 0 || st[i] % 8 != 0) return false;
+    return st[2] >= D && st[2] <= (1LL << 23);
+}
+
+extern "C" int qattn_pack16_strided(const void* x, const long long* strides, void* x_packed, int B, int H, int S, int D, int out_layout,
+                                    void* stream) {
+    if (!x || !x_packed || B <= 0 || H <= 0 || S <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
     if (out_layout != QATTN_LAYOUT_K16FRAG && out_layout != QATTN_LAYOUT_V16FRAG) return QATTN_ERR_INVALID_ARG;
+    if (!strides16_ok(x, strides, D)) return QATTN_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((S + 63) / 64, B * H), block(256);
-    const uint4* xi = (const uint4*)x_rowmajor;
+    const uint4* xi = (const uint4*)x;
     uint4* xo = (uint4*)x_packed;
-#define PK16(DD, LAY) hipLaunchKernelGGL((pack16_tile_kernel<DD, LAY>), grid, block, 0, st, xi, xo, S)
+    const long vd = D / 8;
+    const long sb = strides ? strides[0] / 8 : (long)H * S * vd, sh = strides ? strides[1] / 8 : (long)S * vd, ss = strides ? strides[2] / 8 : vd;
+#define PK16(DD, LAY) hipLaunchKernelGGL((pack16_tile_kernel<DD, LAY>), grid, block, 0, st, xi, xo, S, H, sb, sh, ss)
     if (out_layout == QATTN_LAYOUT_K16FRAG) { if (D == 64) PK16(64, QATTN_LAYOUT_K16FRAG); else if (D == 128) PK16(128, QATTN_LAYOUT_K16FRAG); else PK16(256, QATTN_LAYOUT_K16FRAG); }
     else { if (D == 64) PK16(64, QATTN_LAYOUT_V16FRAG); else if (D == 128) PK16(128, QATTN_LAYOUT_V16FRAG); else PK16(256, QATTN_LAYOUT_V16FRAG); }
 #undef PK16
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }
 
-extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, void* out, float* lse, int B, int Hq,
-                                          int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, int fast_exp,
-                                          void* stream) {
+extern "C" int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H, int S, int D, int out_layout, void* stream) {
+    return qattn_pack16_strided(x_rowmajor, nullptr, x_packed, B, H, S, D, out_layout, stream);
+}
+
+extern "C" int qattn_attention_forward_16_strided(const void* q, const long long* q_strides, const void* k16, const void* v16, void* out, float* lse,
+                                                  int B, int Hq, int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale,
+                                                  int fast_exp, void* stream) {
     if (!q || !k16 || !v16 || !out) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
     if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
     if (fmt != QATTN_FMT_BF16 && fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (!strides16_ok(q, q_strides, D)) return QATTN_ERR_INVALID_ARG;
     Attn16Params p;
     p.q = (const unsigned char*)q; p.k = (const unsigned char*)k16; p.v = (const unsigned char*)v16;
     p.out = out; p.lse = lse;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
+    p.q_rs = 2L * D; p.q_hs = p.q_rs * Sq; p.q_bs = p.q_hs * Hq;
+    if (q_strides) { p.q_bs = 2 * q_strides[0]; p.q_hs = 2 * q_strides[1]; p.q_rs = 2 * q_strides[2]; }
     p.nqb = ceil_div(Sq, kQPerWG16);
     p.ntiles = ceil_div(Skv, 32);
     p.xcd_remap = ((B * Hq) % 8 == 0 && xcd_count() == 8) ? 1 : 0;   // (the block map is written for 8 XCDs, qattn_attn.h)
@@ -408,4 +430,10 @@ extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const 
     else rc = fmt == QATTN_FMT_BF16 ? launch16<256, QATTN_FMT_BF16>(p, is_causal, st) : launch16<256, QATTN_FMT_FP16>(p, is_causal, st);
     if (rc != QATTN_OK) return rc;
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
+}
+
+extern "C" int qattn_attention_forward_16(const void* q, const void* k16, const void* v16, void* out, float* lse, int B, int Hq,
+                                          int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale, int fast_exp,
+                                          void* stream) {
+    return qattn_attention_forward_16_strided(q, nullptr, k16, v16, out, lse, B, Hq, Hkv, Sq, Skv, D, fmt, is_causal, sm_scale, fast_exp, stream);
 }

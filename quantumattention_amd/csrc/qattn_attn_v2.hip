@@ -806,7 +806,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
         const unsigned a0 = part[min(lane, amax_last)], a1 = part[min(lane + 64, amax_last)];
         const unsigned a2 = part[min(lane + 128, amax_last)], a3 = part[min(lane + 192, amax_last)];
         const bool qvalid = qrow < p.Sq;
-        const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
+        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, qvalid ? qrow : 0) + hh * 64);
 #pragma unroll
         for (int s = 0; s < KS; s++)
 #pragma unroll
@@ -944,7 +944,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
         auto qfrag = [&](int s_) -> v8i {
             if (Q16) {
                 const float rinv = 1.0f / scale_q16;
-                const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? row : 0)) * D + hh * 32) * 2) + s_ * 8;
+                const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, qvalid ? row : 0) + hh * 64) + s_ * 8;
                 int2 w[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -975,7 +975,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
             if (on16) {
                 // the fused step has the original 16-bit V at hand: where a flagged row's weight sits on very few keys (kPeakR16) -- its output
                 // carries V's rounding nearly one to one -- the group gets the reference kernel's own P.V numerics (16-bit P, 16-bit V)
-                const unsigned char* vg16 = p.v16 + kv_head * (long)p.Skv * (D * 2);
+                const unsigned char* vg16 = v16_head(p, b, h / (p.Hq / p.Hkv));
                 rescue_rows16_at<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, kg, vg16, row, have, row_lo, row_hi, wave, lane, bh, c,
                                                               [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); });
                 done16 = true;

@@ -344,7 +344,8 @@ inline QuantMoments quant_moments(const unsigned* ws, int B, int Hq, int Hkv, in
 int launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                      float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt, int scale_mode,
                      int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st,
-                     const float* const* ext_amax = nullptr, unsigned* zero_words = nullptr, int zero_n = 0);   // zero_words: a few scratch
+                     const float* const* ext_amax = nullptr, unsigned* zero_words = nullptr, int zero_n = 0,   // zero_words: a few scratch
                      // words of the NEXT kernel in the stream (the attention launch's hand-out counters) that the quantise pass clears on the way
+                     const long long* strides = nullptr);   // element strides {batch, head, row} of q, k, v (9 values; nullptr: dense [B,H,S,D])
 
 }  // namespace qattn

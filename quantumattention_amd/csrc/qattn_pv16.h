@@ -144,7 +144,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     const int qrow = q0 + ql;
     const bool qvalid = qrow < p.Sq;
     const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
-    const unsigned char* vg = p.v16 + kv_head * (long)p.Skv * (D * 2);
+    const unsigned char* vg = v16_head(p, b, h / (p.Hq / p.Hkv));   // (rows p.v16_rs bytes apart: the caller's V may be a strided view)
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + QWG, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
 
@@ -164,7 +164,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
 #pragma unroll
     for (int i = 0; i < VPW; i++) {
         const int r = RPP * (wave * VPW + i) + vr;
-        vsrc0[i] = vg + (long)r * RB + ((vc ^ swz(r)) << 4);
+        vsrc0[i] = vg + (long)r * p.v16_rs + ((vc ^ swz(r)) << 4);
     }
     // piece i of the wave's PW pieces of stage t (K pieces first), into ring slot `slot`
     auto dma_piece = [&](int i, int t, int slot) {
@@ -176,10 +176,10 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
                                              (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
         } else {
             const int j = i - KPW, pc = wave * VPW + j;
-            const unsigned char* vsrc = vsrc0[j >= 0 && j < VPW ? j : 0] + (long)t * (64 * RB);
+            const unsigned char* vsrc = vsrc0[j >= 0 && j < VPW ? j : 0] + (long)t * (64 * p.v16_rs);
             if (t * 64 + 64 > p.Skv) {   // (workgroup-uniform) the head's last, ragged chunk: keys beyond Skv re-read the last row
                 const int r = RPP * pc + vr;
-                vsrc = vg + (long)min(t * 64 + r, p.Skv - 1) * RB + ((vc ^ swz(r)) << 4);
+                vsrc = vg + (long)min(t * 64 + r, p.Skv - 1) * p.v16_rs + ((vc ^ swz(r)) << 4);
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
                                              (__attribute__((address_space(3))) void*)(dst + CH + (pc << 10)), 16, 0, 0);
@@ -205,7 +205,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
                                          p.q_numerics, V16_FMT);   // (the fused step's q, k, v share one 16-bit type)
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q;   // (the block that holds row 0 writes the head's scale, whichever pass runs it)
         const float rinv = 1.0f / scale_q;
-        const uint4* qp = reinterpret_cast<const uint4*>(p.q16 + ((bh * p.Sq + (qvalid ? qrow : 0)) * D + hh * 32) * 2);
+        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, qvalid ? qrow : 0) + hh * 64);
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             int2 w[4];
@@ -608,7 +608,7 @@ __device__ __forceinline__ void rescue_rows16_at(const AttnParams& p, unsigned c
         for (int pc = 0; pc < VCH / 1024; pc++) {
             const int r = 4 * pc + vr;
             const int f = ((r & 3) << 2) | ((r >> 2) & 3);
-            const unsigned char* src = vg16 + (long)min(t * 64 + r, p.Skv - 1) * RB + ((vc ^ f) << 4);   // (keys beyond Skv: the last row; their P is 0)
+            const unsigned char* src = vg16 + (long)min(t * 64 + r, p.Skv - 1) * p.v16_rs + ((vc ^ f) << 4);   // (keys beyond Skv: the last row; their P is 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(varea + (pc << 10)), 16, 0, 0);
         }
     };

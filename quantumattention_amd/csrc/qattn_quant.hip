@@ -89,7 +89,12 @@ struct QuantJob {
     // atomics, and no device-scope fence -- those write back a whole L2 on this chip: a last-block-reduces variant took
     // 517 us instead of 78) for its score-spread estimate (qattn_attn.h: predicted_r).
     float* part;          // [G][kMomentSplits]
+    // where head g = (b, h) of the input starts and how far its rows are apart, in 16-byte vectors (a strided view of [B,H,S,D] with D
+    // innermost and dense; dense: sb = H S D / 8, sh = S D / 8, ss = D / 8)
+    int H;
+    long sb, sh, ss;
 };
+__device__ __forceinline__ const uint4* job_head(const QuantJob& jb, int g) { return jb.x + (long)(g / jb.H) * jb.sb + (long)(g % jb.H) * jb.sh; }
 struct QuantJobs {
     QuantJob j[3];
     unsigned* vexp;       // block-scaled V (else nullptr): [G of v][kMomentSplits] E8M0 bytes, one per 64-key chunk
@@ -105,7 +110,10 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
     if (jb.token || (int)blockIdx.y >= jb.G) return;
     const long vecs_per_group = (long)jb.S * D / 8;
     const long g = blockIdx.y;
-    const uint4* xg = jb.x + g * vecs_per_group;
+    const uint4* xg = job_head(jb, (int)g);
+    // vector i of the head = 16-byte piece (i mod D/8) of row i / (D/8); rows jb.ss vectors apart (dense rows: the plain index)
+    const int lg = 31 - __builtin_clz((unsigned)D >> 3);
+    const long row_gap = jb.ss - (D >> 3);   // (uniform; 0 for a dense head)
     const long per = (vecs_per_group + splits - 1) / splits;
     const long beg = (long)blockIdx.x * per;
     long end = beg + per;
@@ -145,15 +153,19 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
         }
     };
     // kAmaxInFlight independent 16-byte loads in flight per thread (a plain strided loop kept ~2 and ran at 4.8 TB/s)
-    long i = beg + threadIdx.x;
-    for (; i + (kAmaxInFlight - 1) * 256 < end; i += kAmaxInFlight * 256) {
-        uint4 v[kAmaxInFlight];
+    auto sweep = [&](auto at) {
+        long i = beg + threadIdx.x;
+        for (; i + (kAmaxInFlight - 1) * 256 < end; i += kAmaxInFlight * 256) {
+            uint4 v[kAmaxInFlight];
 #pragma unroll
-        for (int u = 0; u < kAmaxInFlight; u++) v[u] = load_nt(&xg[i + u * 256]);
+            for (int u = 0; u < kAmaxInFlight; u++) v[u] = load_nt(at(i + u * 256));
 #pragma unroll
-        for (int u = 0; u < kAmaxInFlight; u++) fold(v[u]);
-    }
-    for (; i < end; i += 256) fold(xg[i]);
+            for (int u = 0; u < kAmaxInFlight; u++) fold(v[u]);
+        }
+        for (; i < end; i += 256) fold(*at(i));
+    };
+    if (row_gap == 0) sweep([&](long i) { return xg + i; });                       // dense head (block-uniform branch)
+    else sweep([&](long i) { return xg + i + (i >> lg) * row_gap; });             // strided view: every thread still folds the same elements
     unsigned m = max(max(m0 & 0xffffu, m0 >> 16), max(m1 & 0xffffu, m1 >> 16));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
@@ -211,18 +223,20 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
         if (tile_first - kQuantTilesPerBlock < 0 && tid == 0) jb.scale[g] = scale;   // (the block that holds tile 0)
     }
     float rinv = 1.0f / scale;
-    const uint4* xg = jb.x + (long)g * S * VPR;
+    const uint4* xg = job_head(jb, g);
+    const int row_vecs = (int)jb.ss;   // 16-byte vectors between consecutive rows (VPR for a dense head)
     const long Sp = (long)((S + 63) / 64) * 64;
     // block-scaled V (vblock_exponent, qattn_common.h): the tile IS the 64-key chunk; its rows are read once, reduced to the
     // chunk's abs-max through LDS, and quantised with the power-of-two scale that the attention kernel gets as one byte
     const bool vblock = layout == QATTN_LAYOUT_VFRAG && jobs.vexp != nullptr;   // uniform over the launch's z slice
     auto load_tile = [&](int tile, uint4 (&dst)[ITERS]) {
+        const uint4* xt = xg + (long)tile * 64 * row_vecs;   // (block-uniform; a row's offset within the tile fits 32 bits: row stride <= 2^23 elements)
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
             const int vec = it * 256 + tid;
-            const int row = tile * 64 + vec / VPR;
+            const int r = vec / VPR, row = tile * 64 + r;
             dst[it] = make_uint4(0, 0, 0, 0);
-            if (row < S) dst[it] = load_nt(&xg[(long)row * VPR + vec % VPR]);
+            if (row < S) dst[it] = load_nt(&xt[(unsigned)r * (unsigned)row_vecs + (unsigned)(vec % VPR)]);
         }
     };
     uint4 held[ITERS];
@@ -363,7 +377,8 @@ extern "C" int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale
     jobs.vexp = nullptr;
     jobs.zero_words = nullptr; jobs.zero_n = 0;
     jobs.nsplit = amax_splits(S, S, D);
-    jobs.j[0] = QuantJob{(const uint4*)x, (uint4*)x8, scale, (unsigned*)workspace, nullptr, G, S, out_layout, head ? 0 : 1, nullptr};
+    jobs.j[0] = QuantJob{(const uint4*)x, (uint4*)x8, scale, (unsigned*)workspace, nullptr, G, S, out_layout, head ? 0 : 1, nullptr,
+                         H, (long)H * S * (D / 8), (long)S * (D / 8), D / 8};
     jobs.j[1] = jobs.j[2] = jobs.j[0];
     jobs.zmap[0] = jobs.zmap[1] = jobs.zmap[2] = 0;
     if (head) {
@@ -437,7 +452,7 @@ extern "C" int qattn_quant_qkv_fp8(const void* q, const void* k, const void* v, 
 int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_fmt, void* q8, void* k8, void* v8, float* scale_q,
                             float* scale_k, float* scale_v, int B, int Hq, int Hkv, int Sq, int Skv, int D, int out_fmt,
                             int scale_mode, int numerics, unsigned* ws, bool skip_q_payload, bool want_moments, bool v_block, hipStream_t st,
-                            const float* const* ext_amax, unsigned* zero_words, int zero_n) {
+                            const float* const* ext_amax, unsigned* zero_words, int zero_n, const long long* strides) {
     const int tok = scale_mode == QATTN_SCALE_TOKEN;
     const unsigned* ext[3] = {nullptr, nullptr, nullptr};
     if (ext_amax)
@@ -450,11 +465,15 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
     const bool vblock = v_block && !tok && (Skv + 63) / 64 <= kMomentSplits;   // V's 256 words per head hold the chunks' scale bytes instead of abs-max words
     jobs.vexp = vblock ? ws + kMomentSplits * (nq + nk) : nullptr;
     jobs.zero_words = zero_words; jobs.zero_n = zero_n;
+    // (strides: element strides {batch, head, row} of q, k, v -> 16-byte vectors; nullptr: dense)
+    const long vd = D / 8;
+    auto sv3 = [&](int t, int H, int S, int i) { return strides ? (long)(strides[3 * t + i] / 8) : i == 0 ? (long)H * S * vd : i == 1 ? (long)S * vd : vd; };
     jobs.j[0] = QuantJob{(const uint4*)q, (uint4*)q8, scale_q, ws, ext[0], B * Hq, Sq, QATTN_LAYOUT_ROWMAJOR, tok,
-                         moments ? part : nullptr};
+                         moments ? part : nullptr, Hq, sv3(0, Hq, Sq, 0), sv3(0, Hq, Sq, 1), sv3(0, Hq, Sq, 2)};
     jobs.j[1] = QuantJob{(const uint4*)k, (uint4*)k8, scale_k, ws + kMomentSplits * nq, ext[1], B * Hkv, Skv, QATTN_LAYOUT_KFRAG, tok,
-                         moments ? part + nq * kMomentSplits : nullptr};
-    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + kMomentSplits * (nq + nk), ext[2], B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0, nullptr};
+                         moments ? part + nq * kMomentSplits : nullptr, Hkv, sv3(1, Hkv, Skv, 0), sv3(1, Hkv, Skv, 1), sv3(1, Hkv, Skv, 2)};
+    jobs.j[2] = QuantJob{(const uint4*)v, (uint4*)v8, scale_v, ws + kMomentSplits * (nq + nk), ext[2], B * Hkv, Skv, QATTN_LAYOUT_VFRAG, 0, nullptr,
+                         Hkv, sv3(2, Hkv, Skv, 0), sv3(2, Hkv, Skv, 1), sv3(2, Hkv, Skv, 2)};
     // the tensors the abs-max pass still has to read: head-wise ones without a caller-supplied abs-max (q, k: not with token-wise
     // scales; V always has one scale per head, or none of its own when block-scaled)
     int npass = 0;

@@ -16,8 +16,8 @@ from tests.conftest import GOLDEN, ROOT
 
 
 def _header_functions():
-    # the drop-in surface (qattn.h) and the measurement entries (qattn_measure.h)
-    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("qattn.h", "qattn_measure.h"))
+    # the drop-in surface (qattn.h), its strided-view entry (qattn_strided.h) and the measurement entries (qattn_measure.h)
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.endswith(".h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(qattn_[a-z0-9_]+)\s*\(", text)))
 
@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert getattr(L, n) is not None, n
     lib = _native.lib()
-    assert lib.qattn_abi_version() == _native.ABI_VERSION == 7
+    assert lib.qattn_abi_version() == _native.ABI_VERSION == 8
 
 
 def _path_table_rows():
