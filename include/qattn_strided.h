@@ -7,10 +7,12 @@
  * abs-max pass, the quantise pass, the attention kernels' in-kernel Q quantisation and their 16-bit-V passes -- takes the strides: nothing is
  * copied, and out / lse / row_path / scale_* are, bit for bit, those of qattn_fp8_quant_attention_forward_ex on dense copies of the views.
  *
- *   strides   9 element strides: {batch, head, row} of q, then of k, then of v, for tensors indexed [b][h][s][d].  D is innermost and dense
- *             (stride 1).  Every stride a non-negative multiple of 8 (rows 16-byte aligned), row stride in [D, 2^23]; q, k, v 16-byte aligned;
- *             else QATTN_ERR_INVALID_ARG.  NULL = dense [B,H,S,D] (= ..._forward_ex).  A stride of 0 broadcasts (e.g. one K / V for every batch).
- *   everything else: as qattn_fp8_quant_attention_forward_ex; `out` is dense [B,Hq,Sq,D] (the reference allocates it so: tk/attention.py:434-437).
+ *   strides   12 element strides: {batch, head, row} of q, then of k, of v and of out, for tensors indexed [b][h][s][d].  D is innermost and
+ *             dense (stride 1).  Every stride a non-negative multiple of 8 (rows 16-byte aligned), row stride in [D, 2^23]; q, k, v, out 16-byte
+ *             aligned; else QATTN_ERR_INVALID_ARG.  NULL = dense [B,H,S,D] (= ..._forward_ex).  A stride of 0 broadcasts an INPUT (e.g. one
+ *             K / V for every batch).  `out` as a view: e.g. the transpose of a dense [B,Sq,Hq,D] buffer, which the caller reshapes to
+ *             [B,Sq,Hq D] for its output projection without a copy (the reference allocates a dense [B,Hq,Sq,D]: tk/attention.py:434-437).
+ *   everything else: as qattn_fp8_quant_attention_forward_ex.
  */
 #ifndef QATTN_STRIDED_H_
 #define QATTN_STRIDED_H_
@@ -28,10 +30,11 @@ int qattn_fp8_quant_attention_forward_strided(const void* q, const void* k, cons
                                               int numerics, int is_causal, float sm_scale, int precision, float* lse, int lse_layout,
                                               unsigned char* row_path, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The 16-bit sibling path (qattn_pack16 / qattn_attention_forward_16 of qattn.h) on views: `strides` / `q_strides` = the three element strides
- * {batch, head, row} of x / of q, same rules, NULL = dense.  k16 / v16 are the K16FRAG / V16FRAG images qattn_pack16[_strided] produced. */
+/* The 16-bit sibling path (qattn_pack16 / qattn_attention_forward_16 of qattn.h) on views: qattn_pack16_strided: `strides` = the three
+ * element strides {batch, head, row} of x; qattn_attention_forward_16_strided: six, of q then of out; same rules, NULL = dense.
+ * k16 / v16 are the K16FRAG / V16FRAG images qattn_pack16[_strided] produced. */
 int qattn_pack16_strided(const void* x, const long long* strides, void* x_packed, int B, int H, int S, int D, int out_layout, void* stream);
-int qattn_attention_forward_16_strided(const void* q, const long long* q_strides, const void* k16, const void* v16, void* out, float* lse,
+int qattn_attention_forward_16_strided(const void* q, const long long* strides, const void* k16, const void* v16, void* out, float* lse,
                                        int B, int Hq, int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale,
                                        int fast_exp, void* stream);
 

@@ -191,6 +191,17 @@ def _strided_ok(t: torch.Tensor) -> bool:
             and (t.shape[2] == 1 or D <= t.stride(2) <= 2 ** 23) and t.data_ptr() % 16 == 0)
 
 
+def empty_output(query: torch.Tensor, dtype, output_layout: str = "contiguous") -> torch.Tensor:
+    """The output tensor of an attention call on `query` [B,H,S,D]: dense (the reference: tk/attention.py:434-437), or -- output_layout
+    "like_query" and a query whose (b, s, h, d) order is dense in memory, i.e. x.view(B, S, H, D).transpose(1, 2) -- the transposed view
+    of a dense [B,S,H,D] tensor (config.attention.output_layout)."""
+    _require(output_layout in ("contiguous", "like_query"), f"output_layout must be 'contiguous' or 'like_query', got {output_layout!r}")
+    B, H, S, D = query.shape
+    if output_layout == "like_query" and not query.is_contiguous() and query.transpose(1, 2).is_contiguous():
+        return torch.empty((B, S, H, D), dtype=dtype, device=query.device).transpose(1, 2)
+    return torch.empty((B, H, S, D), dtype=dtype, device=query.device)
+
+
 def _strides3(t: torch.Tensor):
     """{batch, head, row} element strides of a view `_strided_ok` accepted, as the C entries take them (None: dense)."""
     if t.is_contiguous():
@@ -390,7 +401,8 @@ def pack16(x: torch.Tensor, layout: int) -> torch.Tensor:
 
 
 def attention_forward_16(q: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Tensor, *, Hkv: int, Skv: int,
-                         is_causal: bool, sm_scale: float = 0.0, return_lse: bool = False, fast_exp: bool = False):
+                         is_causal: bool, sm_scale: float = 0.0, return_lse: bool = False, fast_exp: bool = False,
+                         output_layout: str = "contiguous"):
     """q: row-major bf16/fp16 [B,Hq,Sq,D]; k_frag / v_frag: K16FRAG / V16FRAG buffers for [B,Hkv,Skv,D]."""
     _require(q.is_cuda and q.dim() == 4, "attention_forward_16 needs a 4-D device query")
     q = q if _strided_ok(q) else q.contiguous()
@@ -400,9 +412,13 @@ def attention_forward_16(q: torch.Tensor, k_frag: torch.Tensor, v_frag: torch.Te
              and v_frag.numel() * v_frag.element_size() >= L.qattn_16bit_tensor_bytes(LAYOUT_V16FRAG, B, Hkv, Skv, D),
              "k_frag / v_frag are smaller than the fragment layouts of [B,Hkv,Skv,D]")
     with torch.cuda.device(q.device):
-        out = torch.empty((B, Hq, Sq, D), dtype=q.dtype, device=q.device)   # dense, whatever the strides of q
+        out = empty_output(q, q.dtype, output_layout)   # dense whatever the strides of q, unless the caller asks for q's layout
+        strides = None
+        if not (q.is_contiguous() and out.is_contiguous()):
+            dense = (Hq * Sq * D, Sq * D, D)
+            strides = (ctypes.c_longlong * 6)(*[t.stride(i) if t.shape[i] > 1 else dense[i] for t in (q, out) for i in (0, 1, 2)])
         lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if return_lse else None
-        rc = L.qattn_attention_forward_16_strided(q.data_ptr(), _strides3(q), k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
+        rc = L.qattn_attention_forward_16_strided(q.data_ptr(), strides, k_frag.data_ptr(), v_frag.data_ptr(), out.data_ptr(), _ptr(lse),
                                                   B, Hq, Hkv, Sq, Skv, D, fmt_of(q.dtype), int(is_causal), float(sm_scale),
                                                   int(fast_exp), _stream(q))
     _check(rc, "qattn_attention_forward_16_strided")
@@ -422,7 +438,8 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
                                 precision: str = "auto", amax_q: Optional[torch.Tensor] = None,
                                 amax_k: Optional[torch.Tensor] = None, amax_v: Optional[torch.Tensor] = None,
                                 ssq_q: Optional[torch.Tensor] = None, ssq_k: Optional[torch.Tensor] = None,
-                                return_lse: bool = False, lse_layout: int = LSE_NATURAL, return_path: bool = False):
+                                return_lse: bool = False, lse_layout: int = LSE_NATURAL, return_path: bool = False,
+                                output_layout: str = "contiguous"):
     """16-bit q, k, v -> attention output: the quant pre-pass and the attention launch(es) in ONE C call
     (qattn_fp8_quant_attention_forward_ex); the pre-pass skips Q where the attention kernel quantises it itself.
     amax_* / ssq_*: per-head abs-max / sum of squares a producer of q, k, v already has (head-wise scaling only): the
@@ -434,10 +451,11 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
     # strided views (q = x.view(B, S, H, D).transpose(1, 2), slices of a packed QKV projection, ...) go to the kernels as they are
     # (include/qattn_strided.h); only what the kernels cannot address -- a head_dim that is not innermost and dense, rows off 16 bytes -- is copied
     q, k, v = (t if _strided_ok(t) else t.contiguous() for t in (q, k, v))
+    out = empty_output(q, q.dtype, output_layout)
     strides = None
-    if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+    if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and out.is_contiguous()):
         dense = lambda t: (t.shape[1] * t.shape[2] * D, t.shape[2] * D, D)     # (a dimension of size 1 has no stride of its own)
-        strides = (ctypes.c_longlong * 9)(*[t.stride(i) if t.shape[i] > 1 else dense(t)[i] for t in (q, k, v) for i in (0, 1, 2)])
+        strides = (ctypes.c_longlong * 12)(*[t.stride(i) if t.shape[i] > 1 else dense(t)[i] for t in (q, k, v, out) for i in (0, 1, 2)])
     L = lib()
     mode = _scale_mode(scaling)
     dev = q.device
@@ -447,7 +465,6 @@ def fp8_quant_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
     amax_q, ssq_q = _per_head("amax_q", amax_q, B, Hq, dev), _per_head("ssq_q", ssq_q, B, Hq, dev)
     amax_k, amax_v, ssq_k = (_per_head(n, t, B, Hkv, dev) for n, t in (("amax_k", amax_k), ("amax_v", amax_v), ("ssq_k", ssq_k)))
     with torch.cuda.device(dev):
-        out = torch.empty((B, Hq, Sq, D), dtype=q.dtype, device=dev)   # dense, whatever the strides of q (tk/attention.py:434-437)
         q8 = torch.empty((B, Hq, Sq, D), dtype=torch.uint8, device=dev)
         kf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_KFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)
         vf = torch.empty((L.qattn_fp8_tensor_bytes(LAYOUT_VFRAG, B, Hkv, Skv, D),), dtype=torch.uint8, device=dev)

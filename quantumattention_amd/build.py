@@ -26,10 +26,16 @@ SOURCES = ["qattn_quant.hip", "qattn_attn_v2.hip", "qattn_attn_v4.hip", "qattn_a
 # (a unit with a define is compiled through a two-line wrapper file named after the unit, so that -save-temps leaves one .s
 # per unit)
 UNITS = [
-    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0", "QATTN_ONLY_IN16 2"], "qattn_attn_v2_e4m3"),
-    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1", "QATTN_ONLY_IN16 2"], "qattn_attn_v2_e5m2"),
-    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0", "QATTN_ONLY_IN16 3"], "qattn_attn_v2_e4m3_f16"),   # the fused step from fp16 inputs
-    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1", "QATTN_ONLY_IN16 3"], "qattn_attn_v2_e5m2_f16"),
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0", "QATTN_ONLY_IN16 2", "QATTN_STRIDED16 0"], "qattn_attn_v2_e4m3"),
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1", "QATTN_ONLY_IN16 2", "QATTN_STRIDED16 0"], "qattn_attn_v2_e5m2"),
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0", "QATTN_ONLY_IN16 3", "QATTN_STRIDED16 0"], "qattn_attn_v2_e4m3_f16"),   # the fused step from fp16 inputs
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1", "QATTN_ONLY_IN16 3", "QATTN_STRIDED16 0"], "qattn_attn_v2_e5m2_f16"),
+    # the hand-scheduled kernel once more for calls on strided views of q / v / out (fused step only): its dense units above keep
+    # compile-time row sizes -- and with them the exact schedule they had before strides existed (csrc/qattn_attn.h QATTN_STRIDED16)
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0", "QATTN_ONLY_IN16 2", "QATTN_V2_SV 1"], "qattn_attn_v2_e4m3_sv"),
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1", "QATTN_ONLY_IN16 2", "QATTN_V2_SV 1"], "qattn_attn_v2_e5m2_sv"),
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 0", "QATTN_ONLY_IN16 3", "QATTN_V2_SV 1"], "qattn_attn_v2_e4m3_f16_sv"),
+    ("qattn_attn_v2.hip", ["QATTN_ONLY_FMT 1", "QATTN_ONLY_IN16 3", "QATTN_V2_SV 1"], "qattn_attn_v2_e5m2_f16_sv"),
     ("qattn_attn_v4.hip", ["QATTN_ONLY_D 64"], "qattn_attn_v4_d64"),
     ("qattn_attn_v4.hip", ["QATTN_ONLY_D 128"], "qattn_attn_v4_d128"),
     ("qattn_attn_v4.hip", ["QATTN_ONLY_D 256"], "qattn_attn_v4_d256"),

@@ -45,6 +45,12 @@ class attention:
     # reference gets from inlining its quantiser into the compiled region (nn.py:410-418, 484-501).  Eager calls are not affected.
     inline_abs_max_under_compile = os.getenv("QUANTUM_ATTN_INLINE_ABS_MAX", "1") == "1"
 
+    # memory layout of the output: "contiguous" (default) = a fresh dense [B,H,S,D] tensor, as the reference's launcher allocates it
+    # (tk/attention.py:434-437); "like_query" = the layout of the query -- for q = x.view(B, S, H, D).transpose(1, 2) the result is the
+    # transposed view of a dense [B,S,H,D] tensor (what torch's own flash SDPA returns), so that the caller's
+    # `out.transpose(1, 2).reshape(B, S, H * D)` before its output projection is a view instead of a copy.  Same values either way.
+    output_layout = os.getenv("QUANTUM_ATTN_OUTPUT_LAYOUT", "contiguous")
+
     # 16-bit sibling path (attn_func): False = exact v_exp_f32 softmax (default); True = the linear-mantissa 2^x
     # approximation for rows that see >= 1024 keys (+9 % speed, 1.8 % rms error in P: fine for flat rows only)
     fast_exp16 = os.getenv("QUANTUM_ATTN_FAST_EXP16") == "1"

@@ -64,6 +64,7 @@ struct AttnCall {
     unsigned char* path;          // fused entry's per-row path output (else nullptr)
     const long long* q16_strides = nullptr;   // fused step: element strides {batch, head, row} of the 16-bit q / v views (nullptr: dense [B,H,S,D])
     const long long* v16_strides = nullptr;
+    const long long* out_strides = nullptr;   // and of `out`
 };
 
 // attention workspace = [SchedState of the hand-scheduled kernel's causal launches | one flag word per (b, h, 32-row group)]
@@ -145,6 +146,8 @@ int attention_impl(const AttnCall& a, hipStream_t st, DeviceState* ds) {
     p.v16_rs = 2L * a.D; p.v16_hs = p.v16_rs * a.Skv; p.v16_bs = p.v16_hs * a.Hkv;
     if (a.q16 && a.q16_strides) { p.q16_bs = 2 * a.q16_strides[0]; p.q16_hs = 2 * a.q16_strides[1]; p.q16_rs = 2 * a.q16_strides[2]; }
     if (!v_is_16 && a.v16 && a.v16_strides) { p.v16_bs = 2 * a.v16_strides[0]; p.v16_hs = 2 * a.v16_strides[1]; p.v16_rs = 2 * a.v16_strides[2]; }
+    p.o_rs = 2L * a.D; p.o_hs = p.o_rs * a.Sq; p.o_bs = p.o_hs * a.Hq;
+    if (a.out_strides) { p.o_bs = 2 * a.out_strides[0]; p.o_hs = 2 * a.out_strides[1]; p.o_rs = 2 * a.out_strides[2]; }
     if (a.stamps && !(a.q16 && attn_v2_covers(a.D, a.is_causal, a.scale_mode) && a.qk_fmt == QATTN_FMT_E4M3)) return QATTN_ERR_UNSUPPORTED_FMT;
     const bool use_v2 = attn_v2_covers(a.D, a.is_causal, a.scale_mode);
     p.peak_z = (float)p.two_term_keys > kPeakR0 ? 0.5f + logf((float)p.two_term_keys / kPeakR0) : 0.0f;   // see predicted_r
@@ -314,13 +317,14 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
     if (strides) {
         // strided views of the 16-bit inputs (qattn_fp8_quant_attention_forward_strided): D innermost and dense, every row 16-byte aligned,
         // no two rows overlapping is the caller's business; 64 rows of a tensor within 2^31 bytes (32-bit lane offsets of the LDS-DMA requests)
-        const void* base[3] = {q, k, v};
-        for (int t = 0; t < 3; t++) {
+        const void* base[4] = {q, k, v, out};
+        for (int t = 0; t < 4; t++) {
             if ((reinterpret_cast<uintptr_t>(base[t]) & 15u) != 0) return QATTN_ERR_INVALID_ARG;
             for (int i = 0; i < 3; i++)
                 if (strides[3 * t + i] < 0 || strides[3 * t + i] % 8 != 0) return QATTN_ERR_INVALID_ARG;
             if (strides[3 * t + 2] < D || strides[3 * t + 2] > (1LL << 23)) return QATTN_ERR_INVALID_ARG;
         }
+        if ((B > 1 && strides[9] == 0) || (Hq > 1 && strides[10] == 0)) return QATTN_ERR_INVALID_ARG;   // (`out` cannot be a broadcast view)
     }
     if (lse_layout != QATTN_LSE_NATURAL && lse_layout != QATTN_LSE_REFERENCE) return QATTN_ERR_INVALID_ARG;
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
@@ -378,7 +382,7 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                moments ? mom.part_q : ext_moments ? ssq_q : nullptr, moments ? mom.part_k : ext_moments ? ssq_k : nullptr,
                ext_moments ? 1 : mom.nsplit, ext_moments ? 1 : kMomentSplits,
                fuse_q ? q : nullptr, fuse_q ? (q_ext ? reinterpret_cast<const unsigned*>(amax_q) : mom.amax_q) : nullptr, fuse_q ? scale_q : nullptr, numerics,
-               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, v, stamps, zero_in_prepass, row_path, strides, strides ? strides + 6 : nullptr};
+               q_ext ? 1 : mom.nsplit, q_ext ? 1 : kMomentSplits, v, stamps, zero_in_prepass, row_path, strides, strides ? strides + 6 : nullptr, strides ? strides + 9 : nullptr};
     DeviceState* ds = t_profile ? device_state(!stream_is_capturing(st)) : nullptr;
     return attention_impl(a, st, ds);
 }

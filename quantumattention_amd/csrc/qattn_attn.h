@@ -153,14 +153,44 @@ struct AttnParams {
     // Byte strides of batch, head and row; dense: {H S D 2, S D 2, D 2}.  (attention_impl, qattn_api.hip)
     long q16_bs, q16_hs, q16_rs;
     long v16_bs, v16_hs, v16_rs;
+    // `out` may be a strided [B,Hq,Sq,D] view too (D innermost, dense) -- e.g. the transposed view of a [B,Sq,Hq,D] buffer, which a caller
+    // then reshapes to [B,Sq,Hq D] for its output projection without a copy.  Byte strides of batch, head, row; dense: {Hq Sq D 2, Sq D 2, D 2}.
+    long o_bs, o_hs, o_rs;
 };
 
-// first byte of row `row` of head (b, h) of the 16-bit Q / of kv head (b, hkv) of the 16-bit V
-__device__ __forceinline__ const unsigned char* q16_row(const AttnParams& p, int b, int h, int row) {
-    return p.q16 + (long)b * p.q16_bs + (long)h * p.q16_hs + (long)row * p.q16_rs;
+// QATTN_STRIDED16 (a per-translation-unit build switch, build.py): 1 (default) = the kernels of this unit address the 16-bit Q / V and the
+// output through the strides above; 0 = dense arithmetic with compile-time row sizes.  The hand-scheduled kernel is built BOTH ways
+// (qattn_attn_v2_* / qattn_attn_v2_*_sv units; launch_attn_v2 picks by the call's strides): its dense instantiations keep, instruction for
+// instruction, the code they had before strides existed -- any change to that kernel's source moves its schedule by +-0.5 % (three
+// formulations of the strided addressing measured +0.3 / +0.7 / +1.3 % on the dense C2 step: profiles/r06/ab_strided_*.log).
+#ifndef QATTN_STRIDED16
+#define QATTN_STRIDED16 1
+#endif
+constexpr bool kStrided16 = QATTN_STRIDED16 != 0;
+
+// first byte of row `row` of head (b, h) of the 16-bit Q (row_bytes: its dense size) / of kv head (b, hkv) of the 16-bit V
+__device__ __forceinline__ const unsigned char* q16_row(const AttnParams& p, int b, int h, long bh, int row, int row_bytes) {
+    if (kStrided16) return p.q16 + (long)b * p.q16_bs + (long)h * p.q16_hs + (long)row * p.q16_rs;
+    return p.q16 + (bh * p.Sq + row) * row_bytes;
 }
-__device__ __forceinline__ const unsigned char* v16_head(const AttnParams& p, int b, int hkv) {
-    return p.v16 + (long)b * p.v16_bs + (long)hkv * p.v16_hs;
+__device__ __forceinline__ const unsigned char* v16_head(const AttnParams& p, int b, int hkv, long kv_head, int row_bytes) {
+    if (kStrided16) return p.v16 + (long)b * p.v16_bs + (long)hkv * p.v16_hs;
+    return p.v16 + kv_head * (long)p.Skv * row_bytes;
+}
+// bytes between consecutive rows of the 16-bit V
+__device__ __forceinline__ long v16_row_stride(const AttnParams& p, int row_bytes) { return kStrided16 ? p.v16_rs : (long)row_bytes; }
+// byte offset of output row `row` of head bh = b Hq + h (store_o_rows); row_bytes: the dense size of a row
+__device__ __forceinline__ long out_head_offset(const AttnParams& p, int b, int h) { return kStrided16 ? (long)b * p.o_bs + (long)h * p.o_hs : 0L; }
+__device__ __forceinline__ long out_row_offset(const AttnParams& p, long bh, int row, int row_bytes) {
+    if (kStrided16) {
+        const int bhi = (int)bh, b = bhi / p.Hq;   // (32-bit: B Hq < 2^31)
+        return out_head_offset(p, b, bhi - b * p.Hq) + (long)row * p.o_rs;
+    }
+    return (bh * p.Sq + row) * row_bytes;
+}
+// the same with the head's offset at hand (the hand-scheduled kernel's sweeps: no division in the epilogue)
+__device__ __forceinline__ long out_row_offset(const AttnParams& p, long o_head, long bh, int row, int row_bytes) {
+    return kStrided16 ? o_head + (long)row * p.o_rs : (bh * p.Sq + row) * row_bytes;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -373,8 +403,8 @@ __device__ inline v8i lds_read_frag(const unsigned char* base) {
 // rows.  The lanes of the two half-waves hold the 8-byte halves of each 16-byte piece of a row; one v_permlane32_swap per
 // dword pairs them up so that every lane stores 16 contiguous bytes (half the store instructions of the 8-byte form).
 template <int MB>
-__device__ __forceinline__ void store_o_rows(void* out, int out_fmt, const v16f (&o)[MB], float inv, long row, int hh, bool valid) {
-    unsigned char* op = reinterpret_cast<unsigned char*>(out) + row * (MB * 32) * 2 + (hh << 4);
+__device__ __forceinline__ void store_o_rows(void* out, int out_fmt, const v16f (&o)[MB], float inv, long row_offset, int hh, bool valid) {
+    unsigned char* op = reinterpret_cast<unsigned char*>(out) + row_offset + (hh << 4);   // row_offset: out_row_offset() bytes
     const bool bf = out_fmt == QATTN_FMT_BF16;
 #pragma unroll
     for (int m = 0; m < MB; m++)
@@ -710,7 +740,7 @@ __device__ __forceinline__ void rescue_rows_at(const AttnParams& p, unsigned cha
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         const float sv = p.sv ? p.sv[kv_head] : 1.0f;
-        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + row, hh, store && row < p.Sq);
+        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, out_row_offset(p, bh, row, MB * 64), hh, store && row < p.Sq);
         if (p.lse && hh == 0 && store && row < p.Sq)
             p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
     }
@@ -735,6 +765,8 @@ int side_stream_join(hipStream_t st, hipStream_t side);
 // kernel-file entry points (one translation unit per operand format / head dimension, see build.py)
 int launch_attn_v2_e4m3(const AttnParams& p, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v2_e5m2(const AttnParams& p, int causal, int scale_mode, hipStream_t st);
+int launch_attn_v2_e4m3_sv(const AttnParams& p, int causal, int scale_mode, hipStream_t st);   // the same kernels addressing q16 / v16 / out through strides
+int launch_attn_v2_e5m2_sv(const AttnParams& p, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v4_d64(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v4_d128(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
 int launch_attn_v4_d256(const AttnParams& p, int fmt, int causal, int scale_mode, hipStream_t st);
@@ -748,6 +780,12 @@ inline bool attn_v2_covers(int D, int causal, int scale_mode) {
 }
 inline int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
     if (!attn_v2_covers(D, causal, scale_mode)) return QATTN_ERR_UNSUPPORTED_DIM;
+    // dense tensors (every call but a fused one on views): the instantiations with compile-time row sizes (QATTN_STRIDED16 above)
+    const long rb = 2L * D;
+    const bool dense = (!p.q16 || (p.q16_rs == rb && p.q16_hs == rb * p.Sq && p.q16_bs == rb * p.Sq * p.Hq)) &&
+                       (!p.v16 || (p.v16_rs == rb && p.v16_hs == rb * p.Skv && p.v16_bs == rb * p.Skv * p.Hkv)) &&
+                       p.o_rs == rb && p.o_hs == rb * p.Sq && p.o_bs == rb * p.Sq * p.Hq;
+    if (!dense) return fmt == QATTN_FMT_E4M3 ? launch_attn_v2_e4m3_sv(p, causal, scale_mode, st) : launch_attn_v2_e5m2_sv(p, causal, scale_mode, st);
     return fmt == QATTN_FMT_E4M3 ? launch_attn_v2_e4m3(p, causal, scale_mode, st) : launch_attn_v2_e5m2(p, causal, scale_mode, st);
 }
 inline int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {

@@ -47,6 +47,7 @@ struct Attn16Params {
     float sm_log2e;
     int fast_exp;  // opt-in linear-mantissa exponential for rows that see >= kTwoTermKeys keys
     long q_bs, q_hs, q_rs;   // byte strides of q: batch, head, row (a strided view with D innermost; dense: Hq Sq D 2, Sq D 2, D 2)
+    long o_bs, o_hs, o_rs;   // and of out
 };
 
 constexpr int kWaves16 = 4;                        // 128 query rows per workgroup
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kWaves16 * 64, (D == 256 ? 2 : 3)) void attn16_fwd_
     }
     const float inv = 1.0f / l_tot;
     if (qrow < p.Sq) {
-        elt16* op = reinterpret_cast<elt16*>(p.out) + (((long)b * p.Hq + h) * p.Sq + qrow) * D;
+        elt16* op = reinterpret_cast<elt16*>(reinterpret_cast<unsigned char*>(p.out) + (long)b * p.o_bs + (long)h * p.o_hs + (long)qrow * p.o_rs);
 #pragma unroll
         for (int m = 0; m < MB; m++)
 #pragma unroll
@@ -402,7 +403,7 @@ extern "C" int qattn_pack16(const void* x_rowmajor, void* x_packed, int B, int H
     return qattn_pack16_strided(x_rowmajor, nullptr, x_packed, B, H, S, D, out_layout, stream);
 }
 
-extern "C" int qattn_attention_forward_16_strided(const void* q, const long long* q_strides, const void* k16, const void* v16, void* out, float* lse,
+extern "C" int qattn_attention_forward_16_strided(const void* q, const long long* strides, const void* k16, const void* v16, void* out, float* lse,
                                                   int B, int Hq, int Hkv, int Sq, int Skv, int D, int fmt, int is_causal, float sm_scale,
                                                   int fast_exp, void* stream) {
     if (!q || !k16 || !v16 || !out) return QATTN_ERR_INVALID_ARG;
@@ -410,13 +411,17 @@ extern "C" int qattn_attention_forward_16_strided(const void* q, const long long
     if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
     if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
     if (fmt != QATTN_FMT_BF16 && fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (!strides16_ok(q, q_strides, D)) return QATTN_ERR_INVALID_ARG;
+    if (!strides16_ok(q, strides, D) || !strides16_ok(out, strides ? strides + 3 : nullptr, D)) return QATTN_ERR_INVALID_ARG;   // strides: {batch, head, row} of q, then of out
     Attn16Params p;
     p.q = (const unsigned char*)q; p.k = (const unsigned char*)k16; p.v = (const unsigned char*)v16;
     p.out = out; p.lse = lse;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv;
     p.q_rs = 2L * D; p.q_hs = p.q_rs * Sq; p.q_bs = p.q_hs * Hq;
-    if (q_strides) { p.q_bs = 2 * q_strides[0]; p.q_hs = 2 * q_strides[1]; p.q_rs = 2 * q_strides[2]; }
+    p.o_bs = p.q_bs; p.o_hs = p.q_hs; p.o_rs = p.q_rs;
+    if (strides) {
+        p.q_bs = 2 * strides[0]; p.q_hs = 2 * strides[1]; p.q_rs = 2 * strides[2];
+        p.o_bs = 2 * strides[3]; p.o_hs = 2 * strides[4]; p.o_rs = 2 * strides[5];
+    }
     p.nqb = ceil_div(Sq, kQPerWG16);
     p.ntiles = ceil_div(Skv, 32);
     p.xcd_remap = ((B * Hq) % 8 == 0 && xcd_count() == 8) ? 1 : 0;   // (the block map is written for 8 XCDs, qattn_attn.h)

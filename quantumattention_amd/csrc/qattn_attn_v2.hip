@@ -602,7 +602,7 @@ template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool TW
 __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* smem, const unsigned char* kg, const unsigned char* vg,
                                              const unsigned char* qbuf, unsigned* vote, int n_wg, int n_w, int q0, int qrow, int wave,
                                              int lane, long bh, long kv_head, float c, const float* skt, bool check_peaked, LoadQ&& load_q,
-                                             const unsigned* vx, bool first_stages_issued, volatile unsigned* mail) {
+                                             const unsigned* vx, bool first_stages_issued, volatile unsigned* mail, long o_head) {   // o_head: out_head_offset(p, b, h)
     constexpr int MB = D / 32;
     const int hh = lane >> 5;
     WaveState<D, TWO, BYTE> st;
@@ -692,7 +692,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
         // peaked ones are left to whoever recomputes them -- a second store to the same address from another wave is not ordered
         // behind this one
         const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
-        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, bh * p.Sq + qrow, hh, qrow < p.Sq && keep);
+        store_o_rows<MB>(p.out, p.out_fmt, o, sv / l_tot, out_row_offset(p, o_head, bh, qrow, MB * 64), hh, qrow < p.Sq && keep);
         if (p.lse && hh == 0 && qrow < p.Sq && keep)
             p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - SHIFT) + __logf(l_tot) - (BYTE ? kByteLseBias : 0.0f)) * p.lse_mul;
         draw_finish(p, mail, tid_draw, ticket);
@@ -725,7 +725,7 @@ __device__ __forceinline__ int attend_block(const AttnParams& p, unsigned char* 
     // ---- normalise, convert, store
     const float sv = p.sv ? scalar_load_f32(p.sv + kv_head) : 1.0f;
     const float inv = sv / l_tot;
-    store_o_rows<MB>(p.out, p.out_fmt, o, inv, bh * p.Sq + qrow, hh, qrow < p.Sq);
+    store_o_rows<MB>(p.out, p.out_fmt, o, inv, out_row_offset(p, o_head, bh, qrow, MB * 64), hh, qrow < p.Sq);
     draw_finish(p, mail, tid_draw, ticket);
     if (qrow < p.Sq) {
         if (p.lse && hh == 0) {
@@ -806,7 +806,7 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
         const unsigned a0 = part[min(lane, amax_last)], a1 = part[min(lane + 64, amax_last)];
         const unsigned a2 = part[min(lane + 128, amax_last)], a3 = part[min(lane + 192, amax_last)];
         const bool qvalid = qrow < p.Sq;
-        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, qvalid ? qrow : 0) + hh * 64);
+        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, bh, qvalid ? qrow : 0, D * 2) + hh * 64);
 #pragma unroll
         for (int s = 0; s < KS; s++)
 #pragma unroll
@@ -870,7 +870,8 @@ __device__ __forceinline__ int block_pass(const AttnParams& p, unsigned char* sm
     // bf16 rows per block and CU compete with the two live heads' K / V for the XCD's 4 MiB L2.  profiles/r04/ab_c2_q_prefetch_variants.log;
     // the code is in the history up to round 5.)
     return attend_block<D, NW, QK_FMT, V_FMT, CAUSAL, TOKEN, TWO, BYTE, ABL, QREG, Q16, NEFF && !TWO, SUMM && TWO && !BYTE>(
-        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst, mail);
+        p, smem, kg, vg, qbuf, vote, n_wg, n_w, q0, qrow, wave, lane, bh, kv_head, c, skt, check_peaked, load_q, vx, kStagesFirst, mail,
+        out_head_offset(p, b, h));
 }
 
 // The rescue of a block's flagged 32-row groups as a pass of its own, run by whichever workgroup took the queue item (or by the
@@ -944,7 +945,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
         auto qfrag = [&](int s_) -> v8i {
             if (Q16) {
                 const float rinv = 1.0f / scale_q16;
-                const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, qvalid ? row : 0) + hh * 64) + s_ * 8;
+                const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, bh, qvalid ? row : 0, D * 2) + hh * 64) + s_ * 8;
                 int2 w[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -975,7 +976,7 @@ __device__ __forceinline__ void rescue_pass(const AttnParams& p, unsigned char* 
             if (on16) {
                 // the fused step has the original 16-bit V at hand: where a flagged row's weight sits on very few keys (kPeakR16) -- its output
                 // carries V's rounding nearly one to one -- the group gets the reference kernel's own P.V numerics (16-bit P, 16-bit V)
-                const unsigned char* vg16 = v16_head(p, b, h / (p.Hq / p.Hkv));
+                const unsigned char* vg16 = v16_head(p, b, h / (p.Hq / p.Hkv), kv_head, D * 2);
                 rescue_rows16_at<D, NW, QK_FMT, IN16, CAUSAL>(p, smem, kg, vg16, row, have, row_lo, row_hi, wave, lane, bh, c,
                                                               [&](int s_) { return lds_read_frag(qslot + (s_ << 11)); });
                 done16 = true;
@@ -1091,7 +1092,10 @@ __device__ __forceinline__ unsigned run_block(const AttnParams& p, unsigned char
 // other XCDs (S = 8192: -4 %, S = 16384: -2...3 % against one workgroup per block; S = 4096: equal).  A static stride over that
 // order was 6 % slower and balanced pairs of blocks 3-10 % slower in round 2.  Without the state (a caller without a
 // workspace) causal launches use one workgroup per block.
-template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false, bool CHECK = false, int IN16 = QATTN_FMT_BF16>
+// SV: kStrided16 of the translation unit, part of the kernel's NAME only -- the dense (qattn_attn_v2_*) and the strided-view (qattn_attn_v2_*_sv)
+// units instantiate the same template arguments with different bodies (qattn_attn.h QATTN_STRIDED16).
+template <int D, int NW, int QK_FMT, int V_FMT, bool CAUSAL, bool TOKEN, bool BYTE, int ABL = 0, bool Q16 = false, bool CHECK = false, int IN16 = QATTN_FMT_BF16,
+          int SV = QATTN_STRIDED16>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(const AttnParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // two words behind the waves' vote words carry a block number / queue item from thread 0 to the workgroup
@@ -1184,7 +1188,7 @@ static int launch_attn_v2_chk(const AttnParams& pin, hipStream_t st) {
     // the kernel's block loop the drawn successor OUT before anything is parked there (read-before-clobber, see their comments)
     static_assert(kRescue16VBytes + 8 * kQPerWave * 128 == kLdsAll, "the 16-bit-V rescue's V areas + parked Q^T fragments fill the CU's LDS exactly");
     static_assert(64 + 4 * kVxWords <= 4096, "vote words + V scale words fit the last 4 KiB");
-    if constexpr (FMT == QATTN_FMT_E4M3 && Q16 && BYTE && NW == 8 && !TOKEN && IN16 == QATTN_FMT_BF16) {
+    if constexpr (FMT == QATTN_FMT_E4M3 && Q16 && BYTE && NW == 8 && !TOKEN && IN16 == QATTN_FMT_BF16 && !kStrided16) {
         if (p.stamp_buf) {   // measurement entry: the same kernel with the two clock stamps per wave
             auto kern1 = attn_fwd_kernel_v2<D, NW, FMT, FMT, CAUSAL, TOKEN, BYTE, 1024, Q16, CHECK>;
             if (hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return QATTN_ERR_LAUNCH;
@@ -1207,11 +1211,19 @@ static int launch_attn_v2_one(const AttnParams& p, hipStream_t st) {
 // The fused step from fp16 inputs (round 5): the same kernels with IN16 = QATTN_FMT_FP16 -- in-kernel Q quantisation (quant8's fp16 fast
 // path), block-scaled V, 16-bit-V passes on fp16 V and P.  Instantiated in translation units of their own (build.py: -DQATTN_ONLY_IN16=3
 // beside -DQATTN_ONLY_FMT; the other units compile with QATTN_ONLY_IN16=2 and only call the entry points).
-int launch_attn_v2_f16_e4m3(const AttnParams& p, int causal, hipStream_t st);
-int launch_attn_v2_f16_e5m2(const AttnParams& p, int causal, hipStream_t st);
+// Entry points of the strided-view units carry the suffix _sv (build.py: -DQATTN_V2_SV; the dense units: -DQATTN_STRIDED16=0).
+#ifdef QATTN_V2_SV
+#define QATTN_V2_ENTRY(name) name##_sv
+static_assert(kStrided16, "a strided-view unit addresses through the strides");
+#else
+#define QATTN_V2_ENTRY(name) name
+static_assert(!kStrided16, "the dense units of the hand-scheduled kernel are built with -DQATTN_STRIDED16=0 (qattn_attn.h)");
+#endif
+int QATTN_V2_ENTRY(launch_attn_v2_f16_e4m3)(const AttnParams& p, int causal, hipStream_t st);
+int QATTN_V2_ENTRY(launch_attn_v2_f16_e5m2)(const AttnParams& p, int causal, hipStream_t st);
 template <int FMT, bool CAUSAL>
 static int launch_attn_v2_f16(const AttnParams& p, hipStream_t st) {
-    return FMT == QATTN_FMT_E4M3 ? launch_attn_v2_f16_e4m3(p, CAUSAL ? 1 : 0, st) : launch_attn_v2_f16_e5m2(p, CAUSAL ? 1 : 0, st);
+    return FMT == QATTN_FMT_E4M3 ? QATTN_V2_ENTRY(launch_attn_v2_f16_e4m3)(p, CAUSAL ? 1 : 0, st) : QATTN_V2_ENTRY(launch_attn_v2_f16_e5m2)(p, CAUSAL ? 1 : 0, st);
 }
 
 template <int D, int NW, int FMT, bool CAUSAL>
@@ -1227,7 +1239,12 @@ static int launch_attn_v2_t(const AttnParams& pin, int scale_mode, hipStream_t s
         if (p.out_fmt == QATTN_FMT_FP16) return launch_attn_v2_f16<FMT, CAUSAL>(p, st);   // (a translation unit of its own, below)
         return launch_attn_v2_one<D, 8, FMT, CAUSAL, false, true, true>(p, st);
     }
+#ifdef QATTN_V2_SV
+    (void)byte_exp;
+    return QATTN_ERR_UNSUPPORTED_FMT;   // (the strided-view units hold the fused step's kernels only: nothing else reads a 16-bit tensor)
+#else
     return byte_exp ? launch_attn_v2_one<D, NW, FMT, CAUSAL, false, true>(p, st) : launch_attn_v2_one<D, NW, FMT, CAUSAL, false, false>(p, st);
+#endif
 }
 
 // One translation unit per operand format (build.py: -DQATTN_ONLY_FMT=0|1); without the macro the file provides both.
@@ -1237,10 +1254,10 @@ static int launch_attn_v2_fmt(const AttnParams& p, int causal, int scale_mode, h
 }
 #if !defined(QATTN_ONLY_IN16) || QATTN_ONLY_IN16 == 2
 #if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 0
-int launch_attn_v2_e4m3(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E4M3>(p, causal, scale_mode, st); }
+int QATTN_V2_ENTRY(launch_attn_v2_e4m3)(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E4M3>(p, causal, scale_mode, st); }
 #endif
 #if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 1
-int launch_attn_v2_e5m2(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E5M2>(p, causal, scale_mode, st); }
+int QATTN_V2_ENTRY(launch_attn_v2_e5m2)(const AttnParams& p, int causal, int scale_mode, hipStream_t st) { return launch_attn_v2_fmt<QATTN_FMT_E5M2>(p, causal, scale_mode, st); }
 #endif
 #endif
 #if !defined(QATTN_ONLY_IN16) || QATTN_ONLY_IN16 == 3
@@ -1250,10 +1267,10 @@ static int launch_attn_v2_f16_fmt(const AttnParams& p, int causal, hipStream_t s
                   : launch_attn_v2_one<128, 8, FMT, false, false, true, true, QATTN_FMT_FP16>(p, st);
 }
 #if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 0
-int launch_attn_v2_f16_e4m3(const AttnParams& p, int causal, hipStream_t st) { return launch_attn_v2_f16_fmt<QATTN_FMT_E4M3>(p, causal, st); }
+int QATTN_V2_ENTRY(launch_attn_v2_f16_e4m3)(const AttnParams& p, int causal, hipStream_t st) { return launch_attn_v2_f16_fmt<QATTN_FMT_E4M3>(p, causal, st); }
 #endif
 #if !defined(QATTN_ONLY_FMT) || QATTN_ONLY_FMT == 1
-int launch_attn_v2_f16_e5m2(const AttnParams& p, int causal, hipStream_t st) { return launch_attn_v2_f16_fmt<QATTN_FMT_E5M2>(p, causal, st); }
+int QATTN_V2_ENTRY(launch_attn_v2_f16_e5m2)(const AttnParams& p, int causal, hipStream_t st) { return launch_attn_v2_f16_fmt<QATTN_FMT_E5M2>(p, causal, st); }
 #endif
 #endif
 

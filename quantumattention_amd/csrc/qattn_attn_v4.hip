@@ -352,7 +352,7 @@ void attn_fwd_kernel_v4(const AttnParams p, const int qb_lo, const int qb_n, con
     }
     const float sv = p.sv ? p.sv[kv_head] : 1.0f;
     const float inv = sv / l_tot;
-    store_o_rows<MB>(p.out, p.out_fmt, o, inv, bh * p.Sq + qrow, hh, qrow < p.Sq);
+    store_o_rows<MB>(p.out, p.out_fmt, o, inv, out_row_offset(p, bh, qrow, MB * 64), hh, qrow < p.Sq);
     if (!BYTE && p.lse && hh == 0 && qrow < p.Sq)  // ln sum_j exp(score_j) = ln2 * (m*c - shift) + ln(l')
         p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c - kPShift) + __logf(l_tot)) * p.lse_mul;
     if (!BYTE && two && p.path && hh == 0 && qrow < p.Sq) p.path[bh * p.Sq + qrow] = (unsigned char)QATTN_PATH_TWO_TERM;   // (fused entry's debug output)

@@ -144,7 +144,8 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     const int qrow = q0 + ql;
     const bool qvalid = qrow < p.Sq;
     const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
-    const unsigned char* vg = v16_head(p, b, h / (p.Hq / p.Hkv));   // (rows p.v16_rs bytes apart: the caller's V may be a strided view)
+    const unsigned char* vg = v16_head(p, b, h / (p.Hq / p.Hkv), kv_head, RB);   // (the caller's V may be a strided view: rows vrs bytes apart)
+    const long vrs = v16_row_stride(p, RB);
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + QWG, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
 
@@ -164,7 +165,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
 #pragma unroll
     for (int i = 0; i < VPW; i++) {
         const int r = RPP * (wave * VPW + i) + vr;
-        vsrc0[i] = vg + (long)r * p.v16_rs + ((vc ^ swz(r)) << 4);
+        vsrc0[i] = vg + (long)r * vrs + ((vc ^ swz(r)) << 4);
     }
     // piece i of the wave's PW pieces of stage t (K pieces first), into ring slot `slot`
     auto dma_piece = [&](int i, int t, int slot) {
@@ -176,10 +177,10 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
                                              (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
         } else {
             const int j = i - KPW, pc = wave * VPW + j;
-            const unsigned char* vsrc = vsrc0[j >= 0 && j < VPW ? j : 0] + (long)t * (64 * p.v16_rs);
+            const unsigned char* vsrc = vsrc0[j >= 0 && j < VPW ? j : 0] + (long)t * (64 * vrs);
             if (t * 64 + 64 > p.Skv) {   // (workgroup-uniform) the head's last, ragged chunk: keys beyond Skv re-read the last row
                 const int r = RPP * pc + vr;
-                vsrc = vg + (long)min(t * 64 + r, p.Skv - 1) * p.v16_rs + ((vc ^ swz(r)) << 4);
+                vsrc = vg + (long)min(t * 64 + r, p.Skv - 1) * vrs + ((vc ^ swz(r)) << 4);
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
                                              (__attribute__((address_space(3))) void*)(dst + CH + (pc << 10)), 16, 0, 0);
@@ -205,7 +206,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
                                          p.q_numerics, V16_FMT);   // (the fused step's q, k, v share one 16-bit type)
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q;   // (the block that holds row 0 writes the head's scale, whichever pass runs it)
         const float rinv = 1.0f / scale_q;
-        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, qvalid ? qrow : 0) + hh * 64);
+        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, bh, qvalid ? qrow : 0, D * 2) + hh * 64);
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             int2 w[4];
@@ -549,7 +550,7 @@ __device__ __forceinline__ void pv16_block_pass(const AttnParams& p, unsigned ch
     const float l_lo = bcast_low16(lsum[0]), l_hi = bcast_low16(lsum[1]);
     const float l_tot = (lane & 16) ? l_hi : l_lo;
     const unsigned ticket = draw_issue_hook();
-    store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_tot, bh * p.Sq + qrow, hh, qvalid);
+    store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_tot, out_row_offset(p, bh, qrow, MB * 64), hh, qvalid);
     draw_finish_hook(ticket);
 #ifndef QATTN_PV16_STAMP
     if (p.lse && hh == 0 && qvalid) p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (m_run * c) + __logf(l_tot)) * p.lse_mul;
@@ -608,7 +609,7 @@ __device__ __forceinline__ void rescue_rows16_at(const AttnParams& p, unsigned c
         for (int pc = 0; pc < VCH / 1024; pc++) {
             const int r = 4 * pc + vr;
             const int f = ((r & 3) << 2) | ((r >> 2) & 3);
-            const unsigned char* src = vg16 + (long)min(t * 64 + r, p.Skv - 1) * p.v16_rs + ((vc ^ f) << 4);   // (keys beyond Skv: the last row; their P is 0)
+            const unsigned char* src = vg16 + (long)min(t * 64 + r, p.Skv - 1) * v16_row_stride(p, RB) + ((vc ^ f) << 4);   // (keys beyond Skv: the last row; their P is 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(varea + (pc << 10)), 16, 0, 0);
         }
     };
@@ -752,7 +753,7 @@ __device__ __forceinline__ void rescue_rows16_at(const AttnParams& p, unsigned c
         __syncthreads();
     }
     if (wave == 0) {
-        store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_run, bh * p.Sq + row, hh, store && row < p.Sq);
+        store_o_rows<MB>(p.out, p.out_fmt, o, 1.0f / l_run, out_row_offset(p, bh, row, MB * 64), hh, store && row < p.Sq);
         if (p.lse && hh == 0 && store && row < p.Sq) p.lse[bh * p.lse_stride + row] = (0.6931471805599453f * (m_run * c) + __logf(l_run)) * p.lse_mul;
         if (p.path && hh == 0 && store && row < p.Sq) p.path[bh * p.Sq + row] = (unsigned char)QATTN_PATH_V16;
     }

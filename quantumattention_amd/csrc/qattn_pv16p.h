@@ -243,7 +243,8 @@ __device__ __forceinline__ void pv16p_block_pass(const AttnParams& p, unsigned c
     const int qrow = q0 + ql;
     const bool qvalid = qrow < p.Sq;
     const unsigned char* kg = p.k + kv_head * (long)p.nchunks * CH;
-    const unsigned char* vg = v16_head(p, b, h / (p.Hq / p.Hkv));   // (rows p.v16_rs bytes apart)
+    const unsigned char* vg = v16_head(p, b, h / (p.Hq / p.Hkv), kv_head, RB);
+    const long vrs = v16_row_stride(p, RB);   // (a strided view: rows vrs bytes apart)
     const int n_wg = CAUSAL ? min(p.nchunks, (min(q0_wg + QWG, p.Sq) - 1) / 64 + 1) : p.nchunks;
     const int n_w = CAUSAL ? min(n_wg, (q0 + kQPerWave - 1) / 64 + 1) : p.nchunks;
     const int T_ = n_wg + 2;   // iterations t = 0 .. n_wg + 1
@@ -256,7 +257,7 @@ __device__ __forceinline__ void pv16p_block_pass(const AttnParams& p, unsigned c
     for (int i = 0; i < 2; i++) {
         const int r = 4 * (2 * wave + i) + vr;
         const int f = ((r & 3) << 2) | ((r >> 2) & 3);
-        voff_lane[i] = (unsigned)r * (unsigned)p.v16_rs + (unsigned)((vc ^ f) << 4);
+        voff_lane[i] = (unsigned)r * (unsigned)vrs + (unsigned)((vc ^ f) << 4);
     }
     const unsigned kpiece = ((unsigned)wave << 10) + ((unsigned)lane << 4);
     const int last = p.nchunks - 1;
@@ -269,11 +270,11 @@ __device__ __forceinline__ void pv16p_block_pass(const AttnParams& p, unsigned c
         const bool ragged = tv * 64 + 64 > p.Skv;   // (workgroup-uniform) the head's last, ragged chunk: keys beyond Skv re-read the last row
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const unsigned char* src = vg + (long)tv * (64 * p.v16_rs) + voff_lane[i];
+            const unsigned char* src = vg + (long)tv * (64 * vrs) + voff_lane[i];
             if (ragged) {
                 const int r = 4 * (2 * wave + i) + vr;
                 const int f = ((r & 3) << 2) | ((r >> 2) & 3);
-                src = vg + (long)min(tv * 64 + r, p.Skv - 1) * p.v16_rs + ((vc ^ f) << 4);
+                src = vg + (long)min(tv * 64 + r, p.Skv - 1) * vrs + ((vc ^ f) << 4);
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + lds_next + CH + ((2 * wave + i) << 10)), 16, 0, 0);
@@ -293,7 +294,7 @@ __device__ __forceinline__ void pv16p_block_pass(const AttnParams& p, unsigned c
                                          p.q_numerics, V16_FMT);
         if (q0_wg == 0 && tid == 0) p.sq_out[bh] = scale_q;
         const float rinv = 1.0f / scale_q;
-        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, qvalid ? qrow : 0) + hh * 64);
+        const uint4* qp = reinterpret_cast<const uint4*>(q16_row(p, b, h, bh, qvalid ? qrow : 0, D * 2) + hh * 64);
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             int2 w[4];
@@ -466,7 +467,7 @@ __device__ __forceinline__ void pv16p_block_pass(const AttnParams& p, unsigned c
     const float l_lo = bcast_low16(st.lsum[0]), l_hi = bcast_low16(st.lsum[1]);
     const float l_tot = (lane & 16) ? l_hi : l_lo;
     const unsigned ticket = draw_issue_hook();
-    store_o_rows<MB>(p.out, p.out_fmt, st.o, 1.0f / l_tot, bh * p.Sq + qrow, hh, qvalid);
+    store_o_rows<MB>(p.out, p.out_fmt, st.o, 1.0f / l_tot, out_row_offset(p, bh, qrow, MB * 64), hh, qvalid);
     draw_finish_hook(ticket);
     // optional outputs of the fused entry (ABI 7): the log-sum-exp row (the sums are of the ROUNDED 16-bit P, pv16_block_pass) and the row's path
     if (p.lse && hh == 0 && qvalid) p.lse[bh * p.lse_stride + qrow] = (0.6931471805599453f * (st.m_run * st.c) + __logf(l_tot)) * p.lse_mul;

@@ -358,7 +358,7 @@ def _fp8_attention_wrapper(query, key, value, attn_mask=None, dropout_p=0.0, is_
                 ssq_q, ssq_k = _head_sum_sq(query), _head_sum_sq(key)
         return ops.fp8_quant_attention_forward(
             query, key, value, is_causal, scaling_method, _cfg("fp8_format"),
-            _cfg("quant_numerics"), _cfg("precision"), amax_q, amax_k, ssq_q, ssq_k, amax_v, scale=scale)
+            _cfg("quant_numerics"), _cfg("precision"), amax_q, amax_k, ssq_q, ssq_k, amax_v, _cfg("output_layout"), scale=scale)
     if any(t is not None for t in (amax_q, amax_k, ssq_q, ssq_k)):
         raise ValueError("amax_q / amax_k describe 16-bit query / key; fp8 query / key come with scale_q / scale_k")
     return ops.fp8_attention_forward(

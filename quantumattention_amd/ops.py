@@ -17,8 +17,8 @@ _custom_op = torch.library.custom_op
 _register_fake = torch.library.register_fake
 
 
-def _out_like(query: torch.Tensor, value: torch.Tensor) -> torch.Tensor:
-    return torch.empty(query.shape[:-1] + (value.shape[-1],), dtype=value.dtype, device=value.device)
+def _out_like(query: torch.Tensor, value: torch.Tensor, output_layout: str = "contiguous") -> torch.Tensor:
+    return _native.empty_output(query, value.dtype, output_layout)
 
 
 def _check_op_args(attn_mask, dropout_p, scale):
@@ -50,12 +50,12 @@ def attention_forward(
     v_frag = _native.pack16(value, _native.LAYOUT_V16FRAG)
     return _native.attention_forward_16(query, k_frag, v_frag, Hkv=Hkv, Skv=Skv, is_causal=is_causal,
                                         sm_scale=0.0 if scale is None else float(scale),
-                                        fast_exp=bool(config.attention.fast_exp16))
+                                        fast_exp=bool(config.attention.fast_exp16), output_layout=config.attention.output_layout)
 
 
 @_register_fake("quantumattention_amd::attention_forward")
 def _(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, *, scale=None):
-    return _out_like(query, value)
+    return _out_like(query, value, config.attention.output_layout)
 
 
 @_custom_op("quantumattention_amd::fp8_attention_forward", mutates_args=(), device_types=("cuda",))
@@ -125,6 +125,7 @@ def fp8_quant_attention_forward(
     ssq_q: Optional[torch.Tensor] = None,
     ssq_k: Optional[torch.Tensor] = None,
     amax_v: Optional[torch.Tensor] = None,
+    output_layout: str = "contiguous",
     *,
     scale: Optional[float] = None,
 ) -> torch.Tensor:
@@ -139,13 +140,13 @@ def fp8_quant_attention_forward(
     return _native.fp8_quant_attention_forward(
         query, key, value, is_causal=is_causal, scaling=scaling_method, fp8_dtype=_native.fp8_dtype_of(fp8_format),
         numerics=numerics, sm_scale=0.0 if scale is None else float(scale), precision=precision, amax_q=amax_q, amax_k=amax_k,
-        amax_v=amax_v, ssq_q=ssq_q, ssq_k=ssq_k)
+        amax_v=amax_v, ssq_q=ssq_q, ssq_k=ssq_k, output_layout=output_layout)
 
 
 @_register_fake("quantumattention_amd::fp8_quant_attention_forward")
 def _(query, key, value, is_causal=False, scaling_method="head-wise", fp8_format="e4m3", numerics="compiled",
-      precision="auto", amax_q=None, amax_k=None, ssq_q=None, ssq_k=None, amax_v=None, *, scale=None):
-    return _out_like(query, value)
+      precision="auto", amax_q=None, amax_k=None, ssq_q=None, ssq_k=None, amax_v=None, output_layout="contiguous", *, scale=None):
+    return _out_like(query, value, output_layout)
 
 
 @_custom_op("quantumattention_amd::dynamically_quantize_fp8", mutates_args=(), device_types=("cuda",))

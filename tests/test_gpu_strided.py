@@ -115,17 +115,18 @@ def test_c_entry_rejects_strides_it_cannot_use_before_anything_is_written():
     ws = u8(nws)
 
     def call(strides, qptr=None):
-        arr = (ctypes.c_longlong * 9)(*strides) if strides is not None else None
+        arr = (ctypes.c_longlong * 12)(*strides) if strides is not None else None
         return L.qattn_fp8_quant_attention_forward_strided(
             qptr or q.data_ptr(), q.data_ptr(), q.data_ptr(), arr, _native.FMT_BF16, out.data_ptr(), q8.data_ptr(), kf.data_ptr(), vf.data_ptr(),
             sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), None, None, None, None, None, B, H, H, S, S, D, 0, 0, 0, 0, 0.0, 0, None, 0, None,
             ws.data_ptr(), nws, None)
 
-    dense = [H * S * D, S * D, D] * 3
+    dense = [H * S * D, S * D, D] * 4                            # q, k, v, out
     for bad in ([H * S * D, S * D, D - 8] + dense[3:],          # rows closer than D elements
                 dense[:3] + [H * S * D, S * D + 4, D] + dense[6:],   # not a multiple of 8 elements
-                dense[:6] + [-8 * 1024, S * D, D],               # negative
-                dense[:8] + [2 ** 23 + 8]):                      # rows too far apart for the 32-bit lane offsets
+                dense[:6] + [-8 * 1024, S * D, D] + dense[9:],   # negative
+                dense[:8] + [2 ** 23 + 8] + dense[9:],           # rows too far apart for the 32-bit lane offsets
+                dense[:10] + [0, D]):                            # `out` cannot be a broadcast view (two heads on the same rows)
         assert call(bad) == -1      # QATTN_ERR_INVALID_ARG
     assert call(dense, qptr=q.data_ptr() + 2) == -1              # base off 16 bytes
     torch.cuda.synchronize()
@@ -180,3 +181,32 @@ def test_16bit_sibling_path_on_strided_views(layout, B, Hq, Hkv, S, D, causal, d
         assert torch.equal(_native.pack16(k, lay), _native.pack16(k.contiguous(), lay))
     if Hq == Hkv:
         assert torch.equal(qa.attn_func(q, k, v, is_causal=causal), out_d)
+
+
+@pytest.mark.parametrize("D,scaling,causal", [(128, "head-wise", True), (128, "head-wise", False), (64, "head-wise", True), (256, "token-wise", False)])
+def test_output_in_the_layout_of_the_query(D, scaling, causal):
+    """config.attention.output_layout = "like_query": for q = x.view(B, S, H, D).transpose(1, 2) the output is the transposed view of a dense
+    [B,S,H,D] tensor (what torch's flash SDPA returns), so the caller's `out.transpose(1, 2).reshape(B, S, H * D)` is a view.  Every store of
+    every pass (sweep epilogues, rescues, 16-bit-V passes, the templated kernel's launches) goes through the output strides: same values as
+    the dense output, bit for bit; lse and row_path unchanged."""
+    B, H, S = 2, 4, 2304
+    g = torch.Generator(device="cuda").manual_seed(D + S)
+    q, k, v = _views("bshd", B, H, H, S, S, D, torch.bfloat16, g)
+    q[:, :, 5::97] *= 2.2
+    q[:, :, 40::211] *= 4.0
+    kw = dict(is_causal=causal, scaling=scaling, return_lse=True, return_path=True)
+    out_d, lse_d, path_d = _native.fp8_quant_attention_forward(q, k, v, **kw)
+    out_q, lse_q, path_q = _native.fp8_quant_attention_forward(q, k, v, output_layout="like_query", **kw)
+    assert out_d.is_contiguous() and not out_q.is_contiguous() and out_q.transpose(1, 2).is_contiguous()
+    assert out_q.transpose(1, 2).reshape(B, S, H * D).data_ptr() == out_q.data_ptr(), "the caller's reshape must be a view"
+    assert torch.equal(out_q, out_d) and torch.equal(lse_q, lse_d) and torch.equal(path_q, path_d)
+    assert (path_q != 0).any()
+    fn = qa.fp8_attn_func if scaling == "head-wise" else qa.fp8_token_wise_attn_func
+    with qa.config.patch({"attention.output_layout": "like_query"}):
+        api = fn(q, k, v, is_causal=causal)
+        assert api.transpose(1, 2).is_contiguous()
+        # dense inputs keep a dense output; a view the rule does not cover (padded rows) too
+        assert fn(q.contiguous(), k, v, is_causal=causal).is_contiguous()
+        a16 = qa.attn_func(q, k, v, is_causal=causal)
+    assert torch.equal(api, _native.fp8_quant_attention_forward(q, k, v, is_causal=causal, scaling=scaling))
+    assert a16.transpose(1, 2).is_contiguous() and torch.equal(a16, qa.attn_func(q, k, v, is_causal=causal))
