@@ -721,11 +721,23 @@ def run_rank(args):
                         ms_c = event_time(lambda: qa.fp8_attn_func(qv.contiguous(), kv.contiguous(), vv.contiguous(), is_causal=False), 20)
                         same = bool(torch.equal(qa.fp8_attn_func(qv, kv, vv, is_causal=False),
                                                 qa.fp8_attn_func(qv.contiguous(), kv.contiguous(), vv.contiguous(), is_causal=False)))
+                        # what a caller does next: [B,H,S,D] -> [B,S,H D] for its output projection -- a copy of a dense output, a view of
+                        # an output in the query's layout (config.attention.output_layout = "like_query")
+                        reshape = lambda o: o.transpose(1, 2).reshape(4, 4096, 32 * D)
+                        ms_step_reshape = event_time(lambda: reshape(qa.fp8_attn_func(qv, kv, vv, is_causal=False)), 20)
+                        with qa.config.patch({"attention.output_layout": "like_query"}):
+                            ms_lq_reshape = event_time(lambda: reshape(qa.fp8_attn_func(qv, kv, vv, is_causal=False)), 20)
+                            o_lq = qa.fp8_attn_func(qv, kv, vv, is_causal=False)
+                        same_lq = bool(torch.equal(o_lq, qa.fp8_attn_func(qv, kv, vv, is_causal=False))) and reshape(o_lq).data_ptr() == o_lq.data_ptr()
                     fl = flops(4, 32, 4096, 4096, D, False)
                     line["c2_strided_views"] = {"layout": "q, k, v = x.transpose(1, 2) of [B,S,H,D] bf16 tensors (C2 shape)", "ms_per_step_views": ms_v,
                                                 "attn_kernel_ms_views": ams_v, "step_TFLOPs_views": fl / (ms_v * 1e-3) / 1e12,
                                                 "ms_per_step_copies": ms_c, "step_TFLOPs_copies": fl / (ms_c * 1e-3) / 1e12,
-                                                "views_equal_copies_bit_for_bit": same}
+                                                "views_equal_copies_bit_for_bit": same,
+                                                "ms_step_plus_reshape_to_BSHD_dense_output": ms_step_reshape,
+                                                "ms_step_plus_reshape_to_BSHD_output_like_query": ms_lq_reshape,
+                                                "output_like_query_equals_dense_and_reshape_is_a_view": same_lq}
+                    del o_lq
                     del xs, qv, kv, vv
                 except Exception as exc:
                     print(f"[bench] strided-view sample skipped: {exc}", file=sys.stderr)

@@ -49,6 +49,13 @@ for case in range(N):
             if not torch.equal(whole[b:b + 1], fn(q[b:b + 1], k[b:b + 1], v[b:b + 1], is_causal=causal)):
                 msg.append(f"batch element {b} differs from its own call")
                 break
+        if case % 3 == 0:   # the same values as transposed views of [B,S,H,D] tensors, output in the query's layout (include/qattn_strided.h):
+            #                     the persistent / dynamic launches of the strided-view instantiations
+            qv, kv, vv = (t.transpose(1, 2).contiguous().transpose(1, 2) for t in (q, k, v))
+            with qa.config.patch({"attention.output_layout": "like_query" if case % 2 else "contiguous"}):
+                if not torch.equal(whole, fn(qv, kv, vv, is_causal=causal)):
+                    msg.append("call on strided views differs from the dense call")
+            del qv, kv, vv
         if scaling == "head-wise" and case % 2 == 1:   # producer hand-off: the exact per-head abs-max supplied by the caller
             # (under AUTO the sums of squares as well: without them the kernel has no score-spread estimate and wide heads start
             #  one-term -- the same bound, other bits; the fp32 sums differ from the pass's partial sums in the last bits, which

@@ -111,8 +111,13 @@ for case in range(N):
     ref = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal, v_block=vb, fused=True)
     ref_sep = oracle_for_fp8_path(q8, k8, bits16(v), sq, sk, fp8=fp8, v_dtype=dtype, scaling=m, causal=causal)   # (the separate calls: fp8 V with one scale per head, on every row)
     qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    views = bool(rng.integers(2))
+    if views:   # the same values as transposed views of [B,S,H,D] tensors (include/qattn_strided.h): the strided addressing of every kernel, and
+        #         half of the time the output in the query's layout, against the oracle
+        qc, kc, vc = (t.transpose(1, 2).contiguous().transpose(1, 2) for t in (qc, kc, vc))
+    kw_views = {"output_layout": "like_query"} if (views and rng.integers(2)) else {}
     # the fused entry with its row_path: every row is graded against THE oracle of the path the kernel reports (tests/gpu_utils.py)
-    fused, path = fused_call(qc, kc, vc, causal=causal, precision=precision, fp8=fp8, scaling=scaling)
+    fused, path = fused_call(qc, kc, vc, causal=causal, precision=precision, fp8=fp8, scaling=scaling, **kw_views)
     check_path_structure(path, Sq, Skv, causal, precision, D == 128 and scaling == "head-wise")
     if case % 8 == 0:   # ... and the public interface is that call with row_path = NULL
         with qa.config.patch({"attention.precision": precision, "attention.fp8_format": fp8}):
