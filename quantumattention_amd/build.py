@@ -43,7 +43,8 @@ UNITS = [
     ("qattn_quant.hip", [], "qattn_quant"),
     ("qattn_api.hip", [], "qattn_api"),
     ("qattn_probe.hip", [], "qattn_probe"),
-    ("qattn_attn_pv16.hip", [], "qattn_attn_pv16"),
+    ("qattn_attn_pv16.hip", ["QATTN_STRIDED16 0"], "qattn_attn_pv16"),
+    ("qattn_attn_pv16.hip", ["QATTN_PV16_SV 1"], "qattn_attn_pv16_sv"),   # the 16-bit-V launches on strided views (same reason as the _sv units above)
 ]
 # (Until round 5 `--dev` built a second library with -DQATTN_DEV: timing-only ablation instantiations, per-segment cycle stamps, work logs and
 # QATTN_* environment switches.  Round 6 took that scaffolding out of the sources -- identical product ISA, profiles/r06/isa_identity_*.log;

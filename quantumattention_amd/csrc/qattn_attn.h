@@ -774,6 +774,13 @@ int launch_attn_v4_d256(const AttnParams& p, int fmt, int causal, int scale_mode
 // true when the hand-scheduled kernel (qattn_attn_v2.hip) covers the case: D = 128 with head-wise scales.  Token-wise scales
 // need 32 more registers per chunk for the per-key factors, which does not fit 256 registers at two waves per SIMD next
 // to the two-term pass: those calls run on the templated kernel (qattn_attn_v4.hip).
+// true when the 16-bit Q / V the kernels read and the output are dense [B,H,S,D] (the dense units of the twice-built kernels: QATTN_STRIDED16)
+inline bool attn_params_dense(const AttnParams& p, int D) {
+    const long rb = 2L * D;
+    return (!p.q16 || (p.q16_rs == rb && p.q16_hs == rb * p.Sq && p.q16_bs == rb * p.Sq * p.Hq)) &&
+           (!p.v16 || (p.v16_rs == rb && p.v16_hs == rb * p.Skv && p.v16_bs == rb * p.Skv * p.Hkv)) &&
+           p.o_rs == rb && p.o_hs == rb * p.Sq && p.o_bs == rb * p.Sq * p.Hq;
+}
 inline bool attn_v2_covers(int D, int causal, int scale_mode) {
     (void)causal;
     return D == 128 && scale_mode == QATTN_SCALE_HEAD;
@@ -781,11 +788,7 @@ inline bool attn_v2_covers(int D, int causal, int scale_mode) {
 inline int launch_attn_v2(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {
     if (!attn_v2_covers(D, causal, scale_mode)) return QATTN_ERR_UNSUPPORTED_DIM;
     // dense tensors (every call but a fused one on views): the instantiations with compile-time row sizes (QATTN_STRIDED16 above)
-    const long rb = 2L * D;
-    const bool dense = (!p.q16 || (p.q16_rs == rb && p.q16_hs == rb * p.Sq && p.q16_bs == rb * p.Sq * p.Hq)) &&
-                       (!p.v16 || (p.v16_rs == rb && p.v16_hs == rb * p.Skv && p.v16_bs == rb * p.Skv * p.Hkv)) &&
-                       p.o_rs == rb && p.o_hs == rb * p.Sq && p.o_bs == rb * p.Sq * p.Hq;
-    if (!dense) return fmt == QATTN_FMT_E4M3 ? launch_attn_v2_e4m3_sv(p, causal, scale_mode, st) : launch_attn_v2_e5m2_sv(p, causal, scale_mode, st);
+    if (!attn_params_dense(p, D)) return fmt == QATTN_FMT_E4M3 ? launch_attn_v2_e4m3_sv(p, causal, scale_mode, st) : launch_attn_v2_e5m2_sv(p, causal, scale_mode, st);
     return fmt == QATTN_FMT_E4M3 ? launch_attn_v2_e4m3(p, causal, scale_mode, st) : launch_attn_v2_e5m2(p, causal, scale_mode, st);
 }
 inline int launch_attn_v4_full(const AttnParams& p, int D, int fmt, int causal, int scale_mode, hipStream_t st) {

@@ -8,7 +8,18 @@ namespace qattn {
 
 // (two waves per SIMD = 256 registers: D = 256 holds 128 of O^T per lane; one workgroup per CU, which its 144 KiB ring asks for anyway)
 // PP: the two-group loop with a four-stage ring (whole-tensor launches at D = 128, qattn_pv16.h); else the one-group loop, three stages
-template <int D, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool PP>
+// Built twice, like the hand-scheduled kernel (qattn_attn.h QATTN_STRIDED16; build.py: qattn_attn_pv16 with -DQATTN_STRIDED16=0,
+// qattn_attn_pv16_sv with -DQATTN_PV16_SV): with run-time strides in the same source the token-wise D = 128 instantiation came out with its 32 key-scale
+// loads serialised behind s_waitcnt vmcnt(0) -- +40 % on the early rows, +7 % on a token-wise causal step (profiles/r06/ab_strided_token_causal.log).
+// SV: the unit's kStrided16, part of the kernel's NAME only.
+#ifdef QATTN_PV16_SV
+#define QATTN_PV16_ENTRY launch_attn_pv16_sv
+static_assert(kStrided16, "the strided-view unit addresses through the strides");
+#else
+#define QATTN_PV16_ENTRY launch_attn_pv16_dense
+static_assert(!kStrided16, "the dense unit is built with -DQATTN_STRIDED16=0 (qattn_attn.h)");
+#endif
+template <int D, int QK_FMT, int V16_FMT, bool CAUSAL, bool TOKEN, bool PP, int SV = QATTN_STRIDED16>
 __global__ __launch_bounds__(kThreads, 2) void attn_pv16_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     pv16_block_pass<D, kWaves, QK_FMT, V16_FMT, CAUSAL, TOKEN, false, PP ? 4 : 3, PP>(p, smem, (int)threadIdx.x, (int)blockIdx.x, []() { return 0u; }, [](unsigned) {});
@@ -46,7 +57,7 @@ static int launch_d(const AttnParams& p, int qk_fmt, int v16_fmt, int causal, in
                                      : launch_fmt<D, QATTN_FMT_E5M2, QATTN_FMT_FP16>(p, causal, scale_mode, st);
 }
 
-int launch_attn_pv16(const AttnParams& pin, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks) {
+int QATTN_PV16_ENTRY(const AttnParams& pin, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks) {
     AttnParams p = pin;
     p.total_blocks = 0;   // (here: "a whole-tensor launch", read by launch_one)
     if (n_blocks > 0) { p.nqb = n_blocks < p.nqb ? n_blocks : p.nqb; p.risky_lo = p.risky_hi = 0; p.tail_lo = 0; p.total_blocks = 1; }   // (the grid and map_block follow nqb)

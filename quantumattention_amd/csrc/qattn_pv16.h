@@ -763,7 +763,12 @@ __device__ __forceinline__ void rescue_rows16_at(const AttnParams& p, unsigned c
 // workgroup per block (map_block: XCD-contiguous heads, causal blocks heaviest first).
 // n_blocks > 0: only the first n_blocks query blocks of every head (the fused step's early rows on the paths whose main kernel has no
 // 16-bit-V pass of its own: token-wise scales, fp16 inputs).
-int launch_attn_pv16(const AttnParams& p, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks = 0);
+int launch_attn_pv16_dense(const AttnParams& p, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks);
+int launch_attn_pv16_sv(const AttnParams& p, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks);   // q / v16 / out through strides
+inline int launch_attn_pv16(const AttnParams& p, int D, int qk_fmt, int v16_fmt, int causal, int scale_mode, hipStream_t st, int n_blocks = 0) {
+    return attn_params_dense(p, D) ? launch_attn_pv16_dense(p, D, qk_fmt, v16_fmt, causal, scale_mode, st, n_blocks)
+                                   : launch_attn_pv16_sv(p, D, qk_fmt, v16_fmt, causal, scale_mode, st, n_blocks);
+}
 // leading query blocks (of 256 rows) whose first row sees fewer than two_term_keys keys
 inline int pv16_early_blocks(int Sq, int Skv, int causal, int two_term_keys) {
     // block qb sees Skv keys (non-causal) or min(Skv, 256 qb + 1): early while that is below the threshold

@@ -104,16 +104,20 @@ struct QuantJobs {
     int zero_n;
 };
 
-template <int IN_FMT>
+// SV (both pre-pass kernels): false = every tensor of the launch is a dense [G,S,D] array -- the code these kernels had before strided views
+// existed (compile-time row sizes; with the strides read at run time the dense C2 pre-pass measured +1.5 .. 2 us of 114:
+// profiles/r06/kstats_c2_runtime_strides_in_prepass_vs_prev.log; as built now: equal, kstats_prepass_new_vs_prev.log); true = heads and rows
+// through QuantJob::sb / sh / ss.  The launchers pick by the call.
+template <int IN_FMT, bool SV>
 __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, int D, int splits, int zbase) {
     const QuantJob& jb = jobs.j[jobs.zmap[zbase + blockIdx.z]];
     if (jb.token || (int)blockIdx.y >= jb.G) return;
     const long vecs_per_group = (long)jb.S * D / 8;
     const long g = blockIdx.y;
-    const uint4* xg = job_head(jb, (int)g);
-    // vector i of the head = 16-byte piece (i mod D/8) of row i / (D/8); rows jb.ss vectors apart (dense rows: the plain index)
+    const uint4* xg = SV ? job_head(jb, (int)g) : jb.x + g * vecs_per_group;
+    // SV: vector i of the head = 16-byte piece (i mod D/8) of row i / (D/8); rows jb.ss vectors apart
     const int lg = 31 - __builtin_clz((unsigned)D >> 3);
-    const long row_gap = jb.ss - (D >> 3);   // (uniform; 0 for a dense head)
+    const long row_gap = SV ? jb.ss - (D >> 3) : 0L;   // (uniform; 0 for a dense head)
     const long per = (vecs_per_group + splits - 1) / splits;
     const long beg = (long)blockIdx.x * per;
     long end = beg + per;
@@ -153,19 +157,16 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
         }
     };
     // kAmaxInFlight independent 16-byte loads in flight per thread (a plain strided loop kept ~2 and ran at 4.8 TB/s)
-    auto sweep = [&](auto at) {
-        long i = beg + threadIdx.x;
-        for (; i + (kAmaxInFlight - 1) * 256 < end; i += kAmaxInFlight * 256) {
-            uint4 v[kAmaxInFlight];
+    auto at = [&](long i) { return SV ? xg + i + (i >> lg) * row_gap : xg + i; };   // (a strided view: every thread still folds the same elements)
+    long i = beg + threadIdx.x;
+    for (; i + (kAmaxInFlight - 1) * 256 < end; i += kAmaxInFlight * 256) {
+        uint4 v[kAmaxInFlight];
 #pragma unroll
-            for (int u = 0; u < kAmaxInFlight; u++) v[u] = load_nt(at(i + u * 256));
+        for (int u = 0; u < kAmaxInFlight; u++) v[u] = load_nt(at(i + u * 256));
 #pragma unroll
-            for (int u = 0; u < kAmaxInFlight; u++) fold(v[u]);
-        }
-        for (; i < end; i += 256) fold(*at(i));
-    };
-    if (row_gap == 0) sweep([&](long i) { return xg + i; });                       // dense head (block-uniform branch)
-    else sweep([&](long i) { return xg + i + (i >> lg) * row_gap; });             // strided view: every thread still folds the same elements
+        for (int u = 0; u < kAmaxInFlight; u++) fold(v[u]);
+    }
+    for (; i < end; i += 256) fold(*at(i));
     unsigned m = max(max(m0 & 0xffffu, m0 >> 16), max(m1 & 0xffffu, m1 >> 16));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const QuantJobs jobs, i
 #endif
 constexpr int kQuantTilesPerBlock = QATTN_QUANT_TPB;   // 64-row tiles per block of the quantise pass (tuning knob, tools/bin variants)
 
-template <int D, int IN_FMT, int OUT_FMT>
+template <int D, int IN_FMT, int OUT_FMT, bool SV>
 __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, int numerics, int ztop) {
     constexpr int VPR = D / 8;             // 16-byte input vectors per row
     constexpr int ITERS = 64 * VPR / 256;  // vectors per thread
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
         if (tile_first - kQuantTilesPerBlock < 0 && tid == 0) jb.scale[g] = scale;   // (the block that holds tile 0)
     }
     float rinv = 1.0f / scale;
-    const uint4* xg = job_head(jb, g);
-    const int row_vecs = (int)jb.ss;   // 16-byte vectors between consecutive rows (VPR for a dense head)
+    const uint4* xg = SV ? job_head(jb, g) : jb.x + (long)g * S * VPR;
+    const int row_vecs = SV ? (int)jb.ss : VPR;   // 16-byte vectors between consecutive rows
     const long Sp = (long)((S + 63) / 64) * 64;
     // block-scaled V (vblock_exponent, qattn_common.h): the tile IS the 64-key chunk; its rows are read once, reduced to the
     // chunk's abs-max through LDS, and quantised with the power-of-two scale that the attention kernel gets as one byte
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(256) void quant_multi_kernel(const QuantJobs jobs, 
             const int vec = it * 256 + tid;
             const int r = vec / VPR, row = tile * 64 + r;
             dst[it] = make_uint4(0, 0, 0, 0);
-            if (row < S) dst[it] = load_nt(&xt[(unsigned)r * (unsigned)row_vecs + (unsigned)(vec % VPR)]);
+            if (SV) { if (row < S) dst[it] = load_nt(&xt[(unsigned)r * (unsigned)row_vecs + (unsigned)(vec % VPR)]); }
+            else if (row < S) dst[it] = load_nt(&xg[(long)row * VPR + vec % VPR]);
         }
     };
     uint4 held[ITERS];
@@ -354,7 +356,7 @@ extern "C" size_t qattn_quant_workspace_bytes(int B, int H, int S, int D, int sc
 }
 
 template <int D>
-static int launch_quant_multi(const QuantJobs& jobs, int in_fmt, int out_fmt, int numerics, dim3 grid, int ztop, hipStream_t st);
+static int launch_quant_multi(const QuantJobs& jobs, int in_fmt, int out_fmt, int numerics, dim3 grid, int ztop, hipStream_t st, bool sv = false);
 
 // One tensor through the kernels of the fused q/k/v pre-pass (amax_multi_kernel: packed-u16 max, 8 loads in flight, one word per
 // block and no atomics; quant_multi_kernel: conflict-free LDS images): the single-tensor entry used to have kernels of its own,
@@ -383,8 +385,8 @@ extern "C" int qattn_quant_fp8(const void* x, int in_fmt, void* x8, float* scale
     jobs.zmap[0] = jobs.zmap[1] = jobs.zmap[2] = 0;
     if (head) {
         dim3 grid(jobs.nsplit, G, 1), block(256);
-        if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, jobs.nsplit, 0);
-        else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, jobs.nsplit, 0);
+        if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16, false>), grid, block, 0, st, jobs, D, jobs.nsplit, 0);
+        else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16, false>), grid, block, 0, st, jobs, D, jobs.nsplit, 0);
     }
     dim3 grid(((S + 63) / 64 + kQuantTilesPerBlock - 1) / kQuantTilesPerBlock, G, 1);
     int rc;
@@ -422,13 +424,19 @@ extern "C" size_t qattn_quant_qkv_workspace_bytes(int B, int Hq, int Hkv) {
 
 
 template <int D>
-static int launch_quant_multi(const QuantJobs& jobs, int in_fmt, int out_fmt, int numerics, dim3 grid, int ztop, hipStream_t st) {
+static int launch_quant_multi(const QuantJobs& jobs, int in_fmt, int out_fmt, int numerics, dim3 grid, int ztop, hipStream_t st, bool sv) {
     dim3 block(256);
-    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E4M3) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_BF16, QATTN_FMT_E4M3>), grid, block, 0, st, jobs, numerics, ztop);
-    else if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E5M2) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_BF16, QATTN_FMT_E5M2>), grid, block, 0, st, jobs, numerics, ztop);
-    else if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E4M3) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_FP16, QATTN_FMT_E4M3>), grid, block, 0, st, jobs, numerics, ztop);
-    else if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E5M2) hipLaunchKernelGGL((quant_multi_kernel<D, QATTN_FMT_FP16, QATTN_FMT_E5M2>), grid, block, 0, st, jobs, numerics, ztop);
+#define QATTN_QM(IN, OUT)                                                                                                              \
+    do {                                                                                                                               \
+        if (sv) hipLaunchKernelGGL((quant_multi_kernel<D, IN, OUT, true>), grid, block, 0, st, jobs, numerics, ztop);                  \
+        else hipLaunchKernelGGL((quant_multi_kernel<D, IN, OUT, false>), grid, block, 0, st, jobs, numerics, ztop);                    \
+    } while (0)
+    if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E4M3) QATTN_QM(QATTN_FMT_BF16, QATTN_FMT_E4M3);
+    else if (in_fmt == QATTN_FMT_BF16 && out_fmt == QATTN_FMT_E5M2) QATTN_QM(QATTN_FMT_BF16, QATTN_FMT_E5M2);
+    else if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E4M3) QATTN_QM(QATTN_FMT_FP16, QATTN_FMT_E4M3);
+    else if (in_fmt == QATTN_FMT_FP16 && out_fmt == QATTN_FMT_E5M2) QATTN_QM(QATTN_FMT_FP16, QATTN_FMT_E5M2);
     else return QATTN_ERR_UNSUPPORTED_FMT;
+#undef QATTN_QM
     return QATTN_OK;
 }
 
@@ -494,16 +502,22 @@ int qattn::launch_quant_qkv(const void* q, const void* k, const void* v, int in_
         const int splits = amax_splits(Sq, Skv, D);
         dim3 grid(splits, Gmax, npass), block(256);   // (block-scaled V, supplied abs-max: not in the pass)
         if (npass > 0) {
-            if (in_fmt == QATTN_FMT_BF16) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16>), grid, block, 0, st, jobs, D, splits, 0);
-            else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16>), grid, block, 0, st, jobs, D, splits, 0);
+            if (in_fmt == QATTN_FMT_BF16) {
+                if (strides) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16, true>), grid, block, 0, st, jobs, D, splits, 0);
+                else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_BF16, false>), grid, block, 0, st, jobs, D, splits, 0);
+            } else {
+                if (strides) hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16, true>), grid, block, 0, st, jobs, D, splits, 0);
+                else hipLaunchKernelGGL((amax_multi_kernel<QATTN_FMT_FP16, false>), grid, block, 0, st, jobs, D, splits, 0);
+            }
         }
     }
     // the quantise pass walks jobs ztop, ztop-1, ...: with skip_q_payload only v and k (blockIdx.z = 0, 1)
     dim3 grid((((skip_q_payload ? Skv : Smax) + 63) / 64 + kQuantTilesPerBlock - 1) / kQuantTilesPerBlock, skip_q_payload ? B * Hkv : Gmax, skip_q_payload ? 2 : 3);
     int rc;
-    if (D == 64) rc = launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, grid, 2, st);
-    else if (D == 128) rc = launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, grid, 2, st);
-    else rc = launch_quant_multi<256>(jobs, in_fmt, out_fmt, numerics, grid, 2, st);
+    const bool sv = strides != nullptr;
+    if (D == 64) rc = launch_quant_multi<64>(jobs, in_fmt, out_fmt, numerics, grid, 2, st, sv);
+    else if (D == 128) rc = launch_quant_multi<128>(jobs, in_fmt, out_fmt, numerics, grid, 2, st, sv);
+    else rc = launch_quant_multi<256>(jobs, in_fmt, out_fmt, numerics, grid, 2, st, sv);
     if (rc != QATTN_OK) return rc;
     return hipGetLastError() == hipSuccess ? QATTN_OK : QATTN_ERR_LAUNCH;
 }

@@ -347,3 +347,28 @@ def test_compiled_region_carries_the_abs_max_reductions():
         gm = torch._dynamo.export(lambda x_, k_, v_: qa.fp8_attn_func(x_ * 1.5, k_, v_))(x, kl, vl).graph_module
     assert sum(1 for n in gm.graph.nodes if n.op == "call_method" and n.target == "amax") == 3
     torch._dynamo.reset()
+
+
+def test_strided_view_rules_of_the_binding_are_host_logic():
+    """include/qattn_strided.h: which views go to the kernels as they are, which are copied, and where the output lands (no GPU needed: the rules
+    are functions of shapes and strides)."""
+    B, S, H, D = 2, 40, 4, 64
+    x = torch.zeros(B, S, 3 * H, D, dtype=torch.bfloat16)
+    q, k = x[:, :, :H].transpose(1, 2), x[:, :, H:2 * H].transpose(1, 2)
+    assert _native._strided_ok(q) and _native._strided_ok(k) and not q.is_contiguous()
+    assert list(_native._strides3(q)) == [S * 3 * H * D, D, 3 * H * D]
+    assert _native._strides3(q.contiguous()) is None
+    assert _native._strided_ok(torch.zeros(1, H, S, D, dtype=torch.bfloat16).expand(B, H, S, D))          # broadcast over the batch
+    assert not _native._strided_ok(torch.zeros(B, H, D, S, dtype=torch.bfloat16).transpose(2, 3))          # head_dim not innermost
+    assert not _native._strided_ok(torch.zeros(B, H, S, D + 4, dtype=torch.bfloat16)[..., :D])             # rows off 16 bytes
+    assert not _native._strided_ok(torch.zeros(B, H, S, D + 8, dtype=torch.bfloat16)[..., 4:D + 4])        # base off 16 bytes
+    # the output: dense unless asked for the query's layout AND the query is a transposed [B,S,H,D] tensor
+    t = torch.zeros(B, S, H, D, dtype=torch.bfloat16).transpose(1, 2)
+    assert _native.empty_output(t, t.dtype).is_contiguous()
+    o = _native.empty_output(t, t.dtype, "like_query")
+    assert o.shape == t.shape and o.stride() == t.stride() and o.transpose(1, 2).is_contiguous()
+    assert _native.empty_output(t.contiguous(), t.dtype, "like_query").is_contiguous()
+    assert _native.empty_output(q, q.dtype, "like_query").is_contiguous()                                   # a packed-QKV slice: no such layout
+    with pytest.raises(ValueError, match="output_layout"):
+        _native.empty_output(t, t.dtype, "rows")
+    assert qa.config.attention.output_layout == "contiguous"

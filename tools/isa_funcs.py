@@ -30,7 +30,7 @@ def funcs(path):
             continue
         if cur is not None and line.startswith("\t") and not line.startswith("\t."):
             line = re.sub(r"\bs\[\d+:\d+\]", "s[]", line)
-            cur.append(re.sub(r"\bs\d+\b", "s", line).strip())
+            cur.append(re.sub(r"\.LBB\d+_", ".LBB_", re.sub(r"\bs\d+\b", "s", line)).strip())
     return out
 
 
