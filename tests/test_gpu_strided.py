@@ -210,3 +210,24 @@ def test_output_in_the_layout_of_the_query(D, scaling, causal):
         a16 = qa.attn_func(q, k, v, is_causal=causal)
     assert torch.equal(api, _native.fp8_quant_attention_forward(q, k, v, is_causal=causal, scaling=scaling))
     assert a16.transpose(1, 2).is_contiguous() and torch.equal(a16, qa.attn_func(q, k, v, is_causal=causal))
+
+
+def test_torch_compile_on_views_with_the_output_in_the_query_layout():
+    """A user's compiled region that holds [B,S,H*D] activations (the usual module: view -> transpose -> attention -> transpose -> reshape):
+    the fake implementations report the strides the real ops return (output_layout = like_query: the final reshape is a view in the traced
+    graph too), results equal the eager call."""
+    torch.manual_seed(6)
+    B, S, H, D = 2, 1300, 4, 128
+
+    def f(xq, xk, xv):
+        q, k, v = (x.view(B, S, H, D).transpose(1, 2) for x in (xq, xk, xv))
+        o = qa.fp8_attn_func(q, k, v, is_causal=True)
+        return o.transpose(1, 2).reshape(B, S, H * D) + qa.attn_func(q, k, v).transpose(1, 2).reshape(B, S, H * D) * 0
+
+    xs = [torch.randn(B, S, H * D, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+    want = f(*xs)
+    for layout in ("contiguous", "like_query"):
+        with qa.config.patch({"attention.output_layout": layout}):
+            cf = torch.compile(f, backend="aot_eager")
+            assert torch.equal(cf(*xs), want), layout
+            assert torch.equal(f(*xs), want), layout
