@@ -1,4 +1,4 @@
-"""A few launches of one configuration for rocprofv3 --kernel-trace --stats: SHAPE=B,H,S,D CAUSAL=0|1 PREC=auto|fast|accurate MODE=fused|attn|v16|bf16 SCALING=head-wise|token-wise STEPS=n"""
+"""A few launches of one configuration for rocprofv3 --kernel-trace --stats: SHAPE=B,H,S,D CAUSAL=0|1 PREC=auto|fast|accurate MODE=fused|attn|v16|bf16 SCALING=head-wise|token-wise STEPS=n VIEWS=0|1"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +10,8 @@ prec, mode, scaling = os.environ.get("PREC", "auto"), os.environ.get("MODE", "fu
 steps = int(os.environ.get("STEPS", "20"))
 torch.manual_seed(0)
 q, k, v = (torch.randn(B, H, S, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+if os.environ.get("VIEWS", "0") == "1":   # the same values as transposed views of [B,S,H,D] tensors (include/qattn_strided.h)
+    q, k, v = (t.transpose(1, 2).contiguous().transpose(1, 2) for t in (q, k, v))
 if mode == "bf16":   # the 16-bit sibling path (attn_func: qattn_attention_forward_16 behind quantum_attn::attention_forward)
     for _ in range(steps + 3): qa.attn_func(q, k, v, is_causal=causal)
 elif mode == "fused":
