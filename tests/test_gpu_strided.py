@@ -136,20 +136,23 @@ def test_c_entry_rejects_strides_it_cannot_use_before_anything_is_written():
     assert torch.equal(out, _native.fp8_quant_attention_forward(q, q, q, is_causal=False))
 
 
-def test_hip_graph_capture_on_strided_views():
-    """The strides are read on the host at call time: a captured step replays on the same views."""
+@pytest.mark.parametrize("D,token", [(128, False), (64, False), (128, True)])
+def test_hip_graph_capture_on_strided_views(D, token):
+    """The strides are read on the host at call time: a captured step replays on the same views -- the hand-scheduled kernel, and the templated
+    one whose causal calls fork their early rows (the strided 16-bit-V launch) onto the library's side stream inside the capture."""
     g = torch.Generator(device="cuda").manual_seed(9)
-    B, H, S, D = 2, 4, 2304, 128
+    B, H, S = 2, 4, 2304
+    fn = qa.fp8_token_wise_attn_func if token else qa.fp8_attn_func
     x = torch.randn(B, S, 3 * H, D, device="cuda", generator=g).to(torch.bfloat16)
     q, k, v = (x[:, :, i * H:(i + 1) * H].transpose(1, 2) for i in range(3))
-    ref = qa.fp8_attn_func(q.contiguous(), k.contiguous(), v.contiguous(), is_causal=True)
+    ref = fn(q.contiguous(), k.contiguous(), v.contiguous(), is_causal=True)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        qa.fp8_attn_func(q, k, v, is_causal=True)
+        fn(q, k, v, is_causal=True)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):
-            out = qa.fp8_attn_func(q, k, v, is_causal=True)
+            out = fn(q, k, v, is_causal=True)
     torch.cuda.current_stream().wait_stream(s)
     out.zero_()
     graph.replay()
@@ -158,7 +161,7 @@ def test_hip_graph_capture_on_strided_views():
     x.copy_(torch.randn(x.shape, device="cuda", generator=g).to(torch.bfloat16))   # new data in the same storage
     graph.replay()
     torch.cuda.synchronize()
-    assert torch.equal(out, qa.fp8_attn_func(q.contiguous(), k.contiguous(), v.contiguous(), is_causal=True))
+    assert torch.equal(out, fn(q.contiguous(), k.contiguous(), v.contiguous(), is_causal=True))
 
 
 @pytest.mark.parametrize("layout,B,Hq,Hkv,S,D,causal,dtype", [
