@@ -412,6 +412,7 @@ extern "C" int qattn_attention_forward_16_strided(const void* q, const long long
     if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
     if (fmt != QATTN_FMT_BF16 && fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
     if (!strides16_ok(q, strides, D) || !strides16_ok(out, strides ? strides + 3 : nullptr, D)) return QATTN_ERR_INVALID_ARG;   // strides: {batch, head, row} of q, then of out
+    if (strides && ((B > 1 && strides[3] == 0) || (Hq > 1 && strides[4] == 0))) return QATTN_ERR_INVALID_ARG;   // (`out` cannot be a broadcast view)
     Attn16Params p;
     p.q = (const unsigned char*)q; p.k = (const unsigned char*)k16; p.v = (const unsigned char*)v16;
     p.out = out; p.lse = lse;

@@ -184,6 +184,14 @@ def test_16bit_sibling_path_on_strided_views(layout, B, Hq, Hkv, S, D, causal, d
         assert torch.equal(_native.pack16(k, lay), _native.pack16(k.contiguous(), lay))
     if Hq == Hkv:
         assert torch.equal(qa.attn_func(q, k, v, is_causal=causal), out_d)
+    if Hq > 1:   # the C entry refuses an output view in which two heads share their rows
+        L = _native.lib()
+        kf, vf = _native.pack16(k, _native.LAYOUT_K16FRAG), _native.pack16(v, _native.LAYOUT_V16FRAG)
+        qd = q.contiguous()
+        dense = [Hq * S * D, S * D, D]
+        bad = (ctypes.c_longlong * 6)(*(dense + [Hq * S * D, 0, D]))
+        assert L.qattn_attention_forward_16_strided(qd.data_ptr(), bad, kf.data_ptr(), vf.data_ptr(), out_d.data_ptr(), None, B, Hq, Hkv, S, S, D,
+                                                    _native.fmt_of(dtype), int(causal), 0.0, 0, None) == -1
 
 
 @pytest.mark.parametrize("D,scaling,causal", [(128, "head-wise", True), (128, "head-wise", False), (64, "head-wise", True), (256, "token-wise", False)])
