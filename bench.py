@@ -157,7 +157,7 @@ def live_traffic(args):
 def cpu_baseline(args, q, k, v):
     """Reference CPU path (oracle/torch_ref.py: the reference's eager op restated with torch CPU ops) on the host cores of this box.
     The stated configuration -- the whole batch of one GPU -- when a pass fits the time bound (a pass of C2 is about 4 s on the 256 cores of
-    an MI355X host; best of 3), else one batch element (best of 3 .. 12 passes, about 10 s of CPU work); `sample` says which."""
+    an MI355X host), else one batch element; best of 3 .. 12 passes, about 10 s of CPU work either way; `sample` says which."""
     import torch
     from oracle import torch_ref
 
@@ -176,7 +176,7 @@ def cpu_baseline(args, q, k, v):
     one = timed(1)
     nb = args.batch if one * args.batch <= 10.0 else 1   # (the whole batch within about 30 s for three passes)
     best, total, n = (one if nb == 1 else float("inf")), (one if nb == 1 else 0.0), (1 if nb == 1 else 0)
-    while n < 3 or (nb == 1 and total < 10.0 and n < 12):
+    while n < 3 or (total < 10.0 and n < 12):   # (about 10 s of CPU work in either case)
         dt = timed(nb)
         best, total, n = min(best, dt), total + dt, n + 1
     f = flops(nb, args.heads, args.seq, args.seq, args.dim, args.causal)

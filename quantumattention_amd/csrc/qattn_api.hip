@@ -314,6 +314,16 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
                                 int precision, float* lse, int lse_layout, unsigned char* row_path, void* workspace, size_t workspace_bytes,
                                 void* stream, unsigned long long* stamps, const long long* strides = nullptr) {
     if (!q || !k || !v || !out || !q8 || !k8 || !v8 || !scale_q || !scale_k || !scale_v) return QATTN_ERR_INVALID_ARG;
+    if (lse_layout != QATTN_LSE_NATURAL && lse_layout != QATTN_LSE_REFERENCE) return QATTN_ERR_INVALID_ARG;
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
+    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
+    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
+    if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
+    if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
+    if (fp8_fmt != QATTN_FMT_E4M3 && fp8_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
+    if ((amax_q || amax_k || amax_v || ssq_q || ssq_k) && scale_mode != QATTN_SCALE_HEAD) return QATTN_ERR_INVALID_ARG;   // per-head figures
+    if ((ssq_q == nullptr) != (ssq_k == nullptr)) return QATTN_ERR_INVALID_ARG;
     if (strides) {
         // strided views of the 16-bit inputs (qattn_fp8_quant_attention_forward_strided): D innermost and dense, every row 16-byte aligned,
         // no two rows overlapping is the caller's business; 64 rows of a tensor within 2^31 bytes (32-bit lane offsets of the LDS-DMA requests)
@@ -326,16 +336,6 @@ static int quant_attention_impl(const void* q, const void* k, const void* v, int
         }
         if ((B > 1 && strides[9] == 0) || (Hq > 1 && strides[10] == 0)) return QATTN_ERR_INVALID_ARG;   // (`out` cannot be a broadcast view)
     }
-    if (lse_layout != QATTN_LSE_NATURAL && lse_layout != QATTN_LSE_REFERENCE) return QATTN_ERR_INVALID_ARG;
-    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Skv <= 0) return QATTN_ERR_INVALID_ARG;
-    if (D != 64 && D != 128 && D != 256) return QATTN_ERR_UNSUPPORTED_DIM;
-    if (Hq % Hkv != 0) return QATTN_ERR_UNSUPPORTED_DIM;
-    if (scale_mode != QATTN_SCALE_HEAD && scale_mode != QATTN_SCALE_TOKEN) return QATTN_ERR_INVALID_ARG;
-    if (numerics != QATTN_NUMERICS_COMPILED && numerics != QATTN_NUMERICS_EAGER) return QATTN_ERR_INVALID_ARG;
-    if (in_fmt != QATTN_FMT_BF16 && in_fmt != QATTN_FMT_FP16) return QATTN_ERR_UNSUPPORTED_FMT;
-    if (fp8_fmt != QATTN_FMT_E4M3 && fp8_fmt != QATTN_FMT_E5M2) return QATTN_ERR_UNSUPPORTED_FMT;
-    if ((amax_q || amax_k || amax_v || ssq_q || ssq_k) && scale_mode != QATTN_SCALE_HEAD) return QATTN_ERR_INVALID_ARG;   // per-head figures
-    if ((ssq_q == nullptr) != (ssq_k == nullptr)) return QATTN_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < qattn_fp8_quant_attention_workspace_bytes(B, Hq, Hkv, Sq)) return QATTN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool fuse_q = q_fusion_ok(D, in_fmt, scale_mode, is_causal);
